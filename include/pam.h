@@ -1,0 +1,159 @@
+/*
+ * pam.h -- C ABI of libpam_hip.so: the MI355X (gfx950) implementation of the per-frame multi-view 3D pose
+ * hot path of B10532021/Part-Aware_Measurement_for_3D_Pose_Estimation_and_Tracking.
+ *
+ * The reference has no FFI (pure Python); the seams this ABI replaces are the Python call sites below
+ * (paths relative to /root/reference/src).  Host code (the package's ivclabpose.py / tracker.py) binds these with
+ * ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every function returns 0 on success or a negative PAM_E_*
+ * code, with text available from pam_last_error(); no exceptions or callbacks cross the ABI; a handle owns its
+ * device memory, is bound to one GPU and is not thread-safe.  "host" pointers are ordinary host memory, "dev"
+ * pointers are device memory (e.g. torch tensor .data_ptr()); `stream` is a hipStream_t passed as void* (NULL =
+ * the handle's own stream).  Keypoints are rows (y, x, score) in float64 -- the tracker-internal layout the
+ * reference builds at ivclabpose.py:236-244.
+ */
+#ifndef PAM_H
+#define PAM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PAM_J 17            /* joints; hard-coded 17 in the reference too (ivclabpose.py:96) */
+#define PAM_MAX_VIEWS 32    /* per-joint view sets are 32-bit masks */
+#define PAM_MAX_TAPS 16
+#define PAM_EXP_TABLE 64
+
+#define PAM_OK 0
+#define PAM_E_ARG (-1)      /* bad argument / capacity */
+#define PAM_E_HIP (-2)      /* HIP runtime error */
+#define PAM_E_STATE (-3)    /* call order (e.g. cameras not set) */
+#define PAM_E_OVERFLOW (-4) /* a scene ran out of track / hypothesis slots (see out status word) */
+
+/* Matcher hyper-parameters: ivclabpose.py:140-156 (iter_args) + derived tables computed by the host exactly as
+ * the reference's Python does (math.exp / scipy _gaussian_kernel1d), so the device uses bit-identical constants. */
+typedef struct PamParams {
+    double conf_threshold;       /* PIPELINE_COMBINATION.CONF_THRESHOLD            */
+    double epi_threshold;        /* EPI_THRESHOLD   (hypothesis cost scale)         */
+    double init_threshold;       /* INIT_THRESHOLD  (init-path joint filter, f32)   */
+    double joint_threshold;      /* JOINT_THRESHOLD (update-path joint filter)      */
+    double alpha2d;              /* ALPHA2D                                         */
+    double lambda_a;             /* LAMBDA_A                                        */
+    double lambda_t;             /* LAMBDA_T                                        */
+    int32_t n_init;              /* N_INIT                                          */
+    int32_t max_age;             /* MAX_AGE                                         */
+    int32_t count_gate;          /* 10: the literal at IterativeTracker.py:145      */
+    int32_t n_taps_body;         /* radius+1 taps of gaussian_filter1d(sigma)       */
+    int32_t n_taps_arm;          /* radius+1 taps of gaussian_filter1d(arm_sigma)   */
+    int32_t reserved;
+    double taps_body[PAM_MAX_TAPS];   /* w[0]=centre ... w[r]                       */
+    double taps_arm[PAM_MAX_TAPS];
+    double exp_lambda_a[PAM_EXP_TABLE]; /* exp(lambda_a * dt), dt = 0..63           */
+    double w_lambda_t[4];               /* exp(-lambda_t * T), T = 0..3             */
+} PamParams;
+
+typedef struct PamHandle PamHandle;
+
+/* Layout of the per-scene output record (int32 words then float64 words); filled by pam_out_layout(). */
+typedef struct PamOutLayout {
+    int32_t n_views, max_dets, max_tracks, n_scenes;
+    int32_t int_words;      /* int32 words per scene  */
+    int32_t dbl_words;      /* float64 words per scene */
+    /* int32 section: header then per-track blocks (list order = the reference's self.tracks order) */
+    int32_t hdr_words;      /* [0]=n_tracks [1]=status bits [2]=frame_id [3]=n_hyp (debug) */
+    int32_t trk_words;      /* words per track block */
+    /* track block: 0 id,1 state,2 hits,3 age,4 time_since_update,5 emitted,6 n_2d_views,7 V (views offered to the
+     * newest pose),8 history length,9 newest pose time, then order[n_views], matched_det[n_views] (index of the
+     * detection matched THIS frame per camera id or -1), time2d[n_views] (per camera id), nviews[17] */
+    int32_t off_order, off_matched, off_time2d, off_nviews;
+    /* float64 section: [0..3] phase clocks (s): start, after association, after update, after init;
+     * then per track pose3d[17*3], velocity[17*3] */
+    int32_t dbl_hdr_words;
+    int32_t dbl_trk_words;
+} PamOutLayout;
+
+/* ---- life cycle --------------------------------------------------------------------------------------------
+ * replaces: ivclabpose.__init__ (ivclabpose.py:136-158) + IterativeTracker.__init__ (IterativeTracker.py:36-45).
+ * n_scenes > 1 runs that many independent tracker instances per launch (batched scenes, same rig). */
+int pam_create(PamHandle** out, int device, int n_views, int max_dets, int max_tracks, int max_hyps,
+               int n_scenes, const PamParams* params);
+int pam_destroy(PamHandle* h);
+const char* pam_last_error(const PamHandle* h);   /* h may be NULL: last create error */
+const char* pam_version(void);
+
+/* replaces: ivclabpose.GetCameraParameters / Camera.__init__ results (ivclabpose.py:35-46,162-181).  The host computes
+ * P, F, RK_INV (float32) and position (float64) exactly as the reference does and hands them over. */
+int pam_set_cameras(PamHandle* h, const float* P /*C*3*4*/, const float* F /*C*C*3*3*/,
+                    const float* RK_INV /*C*3*3*/, const double* position /*C*3*/);
+
+/* replaces: IterativeTracker.track_restart (IterativeTracker.py:47-50) */
+int pam_reset(PamHandle* h);
+
+int pam_out_layout(const PamHandle* h, PamOutLayout* out);
+
+/* ---- the per-frame step ------------------------------------------------------------------------------------
+ * replaces: IterativeTracker.tracking (IterativeTracker.py:115-180) + output collection (ivclabpose.py:259-287):
+ * association, per-track part-aware view filter + weighted DLT + smoothing + motion, greedy hypothesis
+ * initialisation, life cycle.  State stays on the device.
+ *   n_det : n_scenes*C int32         detections per view
+ *   det   : n_scenes*C*max_dets*17*3 float64 rows (y, x, score)
+ * pam_frame: host buffers in, host record out (out_i: n_scenes*int_words, out_d: n_scenes*dbl_words); synchronous.
+ * pam_frame_dev: device buffers in, record left in the handle's device output buffer; asynchronous on `stream`.
+ * pam_fetch: async copy of the device output record to (pinned) host memory on `stream`. */
+int pam_frame(PamHandle* h, int frame_id, const int32_t* n_det, const double* det, int32_t* out_i, double* out_d);
+int pam_frame_dev(PamHandle* h, void* stream, int frame_id, const int32_t* dev_n_det, const double* dev_det);
+int pam_fetch(PamHandle* h, void* stream, int32_t* host_out_i, double* host_out_d);
+int pam_sync(PamHandle* h, void* stream);
+
+/* ---- per-operator entry points (parity tests; host buffers, synchronous) -----------------------------------*/
+/* Camera.projectPoints_parallel, ivclabpose.py:91-98: n poses (17x3) -> (17x2) in (y, x) */
+int pam_op_project(PamHandle* h, int cid, int n, const double* poses3d, double* out_yx);
+/* affinity build, IterativeTracker.py:137-149: tracks_pose n*17*3, dt n, dets m*17*3 -> aff n*m */
+int pam_op_track_affinity(PamHandle* h, int cid, int n, int m, const double* tracks_pose, const int32_t* dt,
+                          const double* dets, double* aff);
+/* scipy.optimize.linear_sum_assignment call sites IterativeTracker.py:79,150: cost nr*nc (minimise) ->
+ * rows/cols (min(nr,nc) pairs, sorted by row) */
+int pam_op_lsap(PamHandle* h, int nr, int nc, const double* cost, int32_t* rows, int32_t* cols, int32_t* n_pairs);
+/* epipolar_affinity_parallel, matching.py:115-151: V views of one person -> V*V*17 symmetric distances */
+int pam_op_epi_dist(PamHandle* h, int V, const int32_t* cids, const double* pose_mat, double* dist);
+/* epipolar_distance, matching.py:50-91 (OpenCV epilines form): -> 17*2 */
+int pam_op_epi_pair(PamHandle* h, int c1, const double* person1, int c2, const double* person2, double* out);
+/* epipolar_affinity, matching.py:93-113 (float32 storage): -> V*V*17 float32 */
+int pam_op_epi_dist_init(PamHandle* h, int V, const int32_t* cids, const double* pose_mat, float* dist);
+/* Greedy_matching, matching.py:243-295.  mode 0 = 'update' (aff float64, needs pose_j V*3 and next_pose_j 3),
+ * mode 1 = 'init' (aff given as float32).  aff is V*V for ONE joint.  -> keep bitmask over views */
+int pam_op_greedy(PamHandle* h, int mode, int V, const int32_t* cids, const void* aff, const double* pose_j,
+                  const double* next_pose_j, uint32_t* keep_mask);
+/* SVD_pose_kernel_jf, construction.py:89-114: keep_mask[17] view sets, Ts[V] ages -> 17*3 */
+int pam_op_dlt(PamHandle* h, int V, const int32_t* cids, const int32_t* Ts, const double* pose_mat,
+               const uint32_t* keep_mask, const double* next_pose, double* out);
+/* IterTrack.smooth_3dpose, IterativeTracker.py:371-383: hist L*17*3 + raw 17*3 -> 17*3 */
+int pam_op_smooth(PamHandle* h, int L, const double* hist, const double* raw, double* out);
+/* IterTrack.update_motion, IterativeTracker.py:385-395: hist L*17*3 (L>=2) -> float32 17*3 */
+int pam_op_velocity(PamHandle* h, int L, const double* hist, float* vel);
+/* Hypothesis.calculate_cost, hypothesis.py:53-68 */
+int pam_op_hyp_cost(PamHandle* h, int n_members, const int32_t* cids, const double* poses, int o_cid,
+                    const double* o_pose, double* cost, int32_t* veto);
+
+/* ---- image side of a1 (HRNetPose.predict pre/post-processing; call site ivclabpose.py:210) ------------------
+ * pam_preprocess_crops: n person boxes (x, y, w, h float32, in pixels of frame view_of[i]) cropped from BGR uint8
+ * frames (dev pointers, H x W x 3, row pitch W*3), bilinear-resized to out_h x out_w, BGR->RGB, /255, ImageNet
+ * mean/std, written as bf16 NHWC (n, out_h, out_w, 3) -- the channels-last input of the conv stack.
+ * pam_decode_heatmaps: heat-maps (n, hm_h, hm_w, 17) float32 NHWC or (n,17,hm_h,hm_w) NCHW (nchw flag) -> per person
+ * hard arg-max per joint mapped through the box; writes float64 rows (y, x, score) into the tracker's det buffer
+ * slot (view_of[i], slot_of[i]).  All pointers are device pointers; asynchronous on `stream`. */
+int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames /*dev array of n_views frame ptrs*/,
+                         int frame_h, int frame_w, const int32_t* dev_view_of, const float* dev_boxes,
+                         int out_h, int out_w, void* dev_out_bf16);
+int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw, int hm_h, int hm_w,
+                        const int32_t* dev_view_of, const int32_t* dev_slot_of, const float* dev_boxes,
+                        int max_dets, double* dev_det, float* dev_kp_xyc /*optional n*17*3 (x,y,conf) or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAM_H */

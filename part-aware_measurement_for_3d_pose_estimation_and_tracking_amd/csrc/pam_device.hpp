@@ -1,0 +1,381 @@
+// Device functions of the matching / triangulation path (gfx950, wave64).  Shared by the fused per-frame kernel and
+// by the per-operator test kernels, so what the parity tests exercise is what the frame step runs.
+// All association math is float64 (the reference's NumPy dtype); float32 only where the reference stores float32.
+// Citations: /root/reference/src/...
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pam.h"
+
+#define J PAM_J
+#define J3 (PAM_J * 3)
+
+namespace pam {
+
+struct CamSet {              // device-resident camera constants of a rig (a18)
+    const float* P;          // C*12   float32 (ivclabpose.py:163)
+    const float* F;          // C*C*9  float32, F[a][b]: x_a^T F x_b = 0 (ivclabpose.py:166-177)
+    const float* RKINV;      // C*9    float32 (ivclabpose.py:41)
+    const double* pos;       // C*3    float64 (ivclabpose.py:45-46)
+    int C;
+};
+
+// ---- a3: pin-hole projection, ivclabpose.py:91-98 --------------------------------------------------------------
+__device__ __forceinline__ void project_point(const float* __restrict__ P, double X, double Y, double Z,
+                                              double& u, double& v) {
+    double h0 = (double)P[0] * X + (double)P[1] * Y + (double)P[2] * Z + (double)P[3];
+    double h1 = (double)P[4] * X + (double)P[5] * Y + (double)P[6] * Z + (double)P[7];
+    double h2 = (double)P[8] * X + (double)P[9] * Y + (double)P[10] * Z + (double)P[11];
+    u = h0 / h2;
+    v = h1 / h2;
+}
+
+// ---- a3+a4: track <-> detection affinity for one (track, detection) pair, IterativeTracker.py:137-149 -----------
+// pose3d 17x3 world; det 17x3 rows (y, x, score); alpha_dt = alpha2d*dt; exp_ldt = exp(lambda_a*dt)
+__device__ inline double track_det_affinity(const float* __restrict__ P, const double* __restrict__ pose3d,
+                                            const double* __restrict__ det, double alpha_dt, double exp_ldt, int gate) {
+    double sum = 0.0;
+    int cnt = 0;
+    for (int j = 0; j < J; ++j) {
+        double u, v;
+        project_point(P, pose3d[j * 3 + 0], pose3d[j * 3 + 1], pose3d[j * 3 + 2], u, v);
+        double dy = v - det[j * 3 + 0];
+        double dx = u - det[j * 3 + 1];
+        double c = 1.0 - sqrt(dy * dy + dx * dx) / alpha_dt;
+        if (c > 0.0) { sum += c; ++cnt; }
+    }
+    double aff = (cnt > gate) ? sum / (double)cnt : 0.0;
+    aff = aff / exp_ldt;
+    if (aff != aff) aff = 0.0;
+    return aff;
+}
+
+// ---- a5: rectangular LSAP (SciPy linear_sum_assignment restated), call sites IterativeTracker.py:79,150 ---------
+struct LsapScratch {         // N = max(nr, nc) entries each
+    double* u; double* v; double* spc;
+    int* path; int* col4row; int* row4col; int* remaining;
+    unsigned char* SR; unsigned char* SC;
+};
+__host__ __device__ inline size_t lsap_scratch_bytes(int N) {
+    return (size_t)N * (3 * sizeof(double) + 4 * sizeof(int)) + 2 * ((N + 7) & ~7);
+}
+__device__ inline LsapScratch lsap_carve(void* base, int N) {
+    LsapScratch s;
+    char* p = (char*)base;
+    s.u = (double*)p; p += sizeof(double) * N;
+    s.v = (double*)p; p += sizeof(double) * N;
+    s.spc = (double*)p; p += sizeof(double) * N;
+    s.path = (int*)p; p += sizeof(int) * N;
+    s.col4row = (int*)p; p += sizeof(int) * N;
+    s.row4col = (int*)p; p += sizeof(int) * N;
+    s.remaining = (int*)p; p += sizeof(int) * N;
+    s.SR = (unsigned char*)p; p += (N + 7) & ~7;
+    s.SC = (unsigned char*)p;
+    return s;
+}
+// minimise sum sign*cost[r*ld + c]; writes pairs sorted by row; returns number of pairs (min(nr,nc)) or -1 (infeasible)
+__device__ inline int lsap_solve(int nr0, int nc0, const double* cost, int ld, double sign, LsapScratch s,
+                                 int* rows_out, int* cols_out) {
+    if (nr0 == 0 || nc0 == 0) return 0;
+    const bool tr = nc0 < nr0;                       // tall matrices are solved transposed
+    const int nr = tr ? nc0 : nr0, nc = tr ? nr0 : nc0;
+#define PAM_COST(i, j) (sign * (tr ? cost[(j) * ld + (i)] : cost[(i) * ld + (j)]))
+    for (int i = 0; i < nr; ++i) { s.u[i] = 0.0; s.col4row[i] = -1; }
+    for (int j = 0; j < nc; ++j) { s.v[j] = 0.0; s.row4col[j] = -1; s.path[j] = -1; }
+    const double INF = __builtin_huge_val();
+    for (int cur = 0; cur < nr; ++cur) {
+        for (int j = 0; j < nc; ++j) { s.spc[j] = INF; s.SC[j] = 0; s.remaining[j] = nc - 1 - j; }
+        for (int i = 0; i < nr; ++i) s.SR[i] = 0;
+        int num_rem = nc, i = cur, sink = -1;
+        double min_val = 0.0;
+        while (sink == -1) {
+            int index = -1;
+            double lowest = INF;
+            s.SR[i] = 1;
+            const double ui = s.u[i];
+            for (int it = 0; it < num_rem; ++it) {
+                const int j = s.remaining[it];
+                const double r = min_val + PAM_COST(i, j) - ui - s.v[j];
+                double sp = s.spc[j];
+                if (r < sp) { s.path[j] = i; s.spc[j] = r; sp = r; }
+                if (sp < lowest || (sp == lowest && s.row4col[j] == -1)) { lowest = sp; index = it; }
+            }
+            min_val = lowest;
+            if (min_val == INF) return -1;
+            const int j = s.remaining[index];
+            if (s.row4col[j] == -1) sink = j; else i = s.row4col[j];
+            s.SC[j] = 1;
+            s.remaining[index] = s.remaining[--num_rem];
+        }
+        s.u[cur] += min_val;
+        for (int r = 0; r < nr; ++r)
+            if (s.SR[r] && r != cur) s.u[r] += min_val - s.spc[s.col4row[r]];
+        for (int c = 0; c < nc; ++c)
+            if (s.SC[c]) s.v[c] -= min_val - s.spc[c];
+        int j = sink;
+        for (;;) {
+            const int ii = s.path[j];
+            s.row4col[j] = ii;
+            const int t = s.col4row[ii]; s.col4row[ii] = j; j = t;
+            if (ii == cur) break;
+        }
+    }
+#undef PAM_COST
+    int n = 0;
+    if (tr) {   // solved rows are original columns; emit sorted by original row
+        for (int r = 0; r < nc; ++r)
+            if (s.row4col[r] != -1) { rows_out[n] = r; cols_out[n] = s.row4col[r]; ++n; }
+    } else {
+        for (int r = 0; r < nr; ++r) { rows_out[n] = r; cols_out[n] = s.col4row[r]; ++n; }
+    }
+    return n;
+}
+
+// ---- a7: epipolar point-to-line distance, vectorised ("parallel") form, matching.py:115-151 ---------------------
+// distance of point j to the line induced in its view by point i:  l = F[ci][cj]^T (xi, yi, 1)
+__device__ __forceinline__ double epi_directed(const float* __restrict__ Fij, double xi, double yi, double xj, double yj) {
+    double l0 = (double)Fij[0] * xi + (double)Fij[3] * yi + (double)Fij[6];
+    double l1 = (double)Fij[1] * xi + (double)Fij[4] * yi + (double)Fij[7];
+    double l2 = (double)Fij[2] * xi + (double)Fij[5] * yi + (double)Fij[8];
+    double nu = sqrt(l0 * l0 + l1 * l1);
+    if (nu == 0.0) nu = 1.0;
+    l0 /= nu; l1 /= nu; l2 /= nu;
+    double nrm = l0 * l0 + l1 * l1;
+    if (nrm == 0.0) nrm = 1.0;
+    return fabs(xj * l0 + yj * l1 + l2) / sqrt(nrm);
+}
+// symmetric distance between view a (camera ca, point pa=(y,x,.)) and view b; 0 for the same camera (matching.py:133-134)
+__device__ __forceinline__ double epi_sym(const CamSet& cs, int ca, const double* pa, int cb, const double* pb) {
+    if (ca == cb) return 0.0;
+    const float* Fab = cs.F + ((size_t)ca * cs.C + cb) * 9;
+    const float* Fba = cs.F + ((size_t)cb * cs.C + ca) * 9;
+    double dab = epi_directed(Fab, pa[1], pa[0], pb[1], pb[0]);
+    double dba = epi_directed(Fba, pb[1], pb[0], pa[1], pa[0]);
+    return (dab + dba) / 2.0;
+}
+
+// ---- a15: OpenCV computeCorrespondEpilines form, matching.py:50-91 ----------------------------------------------
+// F = cams[c1].F[c2]; d1 = distance of p1 to the line F p2, d2 = distance of p2 to the line F^T p1
+__device__ __forceinline__ void epi_pair_cv(const float* __restrict__ F, double x1, double y1, double x2, double y2,
+                                            double& d1, double& d2) {
+    // line in image 2 from p1 (whichImage = 2 -> F transposed)
+    double a = (double)F[0] * x1 + (double)F[3] * y1 + (double)F[6];
+    double b = (double)F[1] * x1 + (double)F[4] * y1 + (double)F[7];
+    double c = (double)F[2] * x1 + (double)F[5] * y1 + (double)F[8];
+    double nu = a * a + b * b;
+    nu = (nu != 0.0) ? 1.0 / sqrt(nu) : 1.0;
+    a *= nu; b *= nu; c *= nu;
+    d2 = fabs(x2 * a + y2 * b + c) / sqrt(a * a + b * b);
+    // line in image 1 from p2 (whichImage = 1)
+    double e = (double)F[0] * x2 + (double)F[1] * y2 + (double)F[2];
+    double f = (double)F[3] * x2 + (double)F[4] * y2 + (double)F[5];
+    double g = (double)F[6] * x2 + (double)F[7] * y2 + (double)F[8];
+    double mu = e * e + f * f;
+    mu = (mu != 0.0) ? 1.0 / sqrt(mu) : 1.0;
+    e *= mu; f *= mu; g *= mu;
+    d1 = fabs(x1 * e + y1 * f + g) / sqrt(e * e + f * f);
+}
+// float32-stored symmetric init-path distance for views a<b in list order, matching.py:99-109
+__device__ __forceinline__ float epi_sym_init(const CamSet& cs, int ca, const double* pa, int cb, const double* pb) {
+    if (ca == cb) return 0.0f;
+    double d1, d2;
+    epi_pair_cv(cs.F + ((size_t)ca * cs.C + cb) * 9, pa[1], pa[0], pb[1], pb[0], d1, d2);
+    return (float)((d1 + d2) / 2.0);
+}
+
+// ---- a8: back-projected ray to predicted joint, matching.py:10-17 + calculate.py:26-32 --------------------------
+__device__ inline double ray_point_dist(const float* __restrict__ RK, const double* __restrict__ pos, double x, double y,
+                                        const double* __restrict__ Xp) {
+    double dx = (double)RK[0] * x + (double)RK[1] * y + (double)RK[2];
+    double dy = (double)RK[3] * x + (double)RK[4] * y + (double)RK[5];
+    double dz = (double)RK[6] * x + (double)RK[7] * y + (double)RK[8];
+    double n = sqrt(dx * dx + dy * dy + dz * dz);
+    dx /= n; dy /= n; dz /= n;
+    double ex = (pos[0] + dx) - pos[0], ey = (pos[1] + dy) - pos[1], ez = (pos[2] + dz) - pos[2];
+    double wx = pos[0] - Xp[0], wy = pos[1] - Xp[1], wz = pos[2] - Xp[2];
+    double cx = ey * wz - ez * wy, cy = ez * wx - ex * wz, cz = ex * wy - ey * wx;
+    return sqrt(cx * cx + cy * cy + cz * cz) / sqrt(ex * ex + ey * ey + ez * ez);
+}
+
+// ---- a8/a16: greedy per-joint view filter, matching.py:243-295 --------------------------------------------------
+// conf[r] = bit c set iff c > r and affinity(r,c) < 0.  Pairs are visited row-major; a pair is skipped once either
+// member is gone.  update: drop r iff ray[r] > ray[c] else c.  init: drop c iff sum[r] > sum[c] else r.
+__device__ inline uint32_t greedy_keep_update(int V, const uint32_t* conf, const double* ray) {
+    uint32_t alive = (V >= 32) ? 0xffffffffu : ((1u << V) - 1u);
+    for (int r = 0; r < V; ++r) {
+        uint32_t m = conf[r];
+        while (m && ((alive >> r) & 1u)) {
+            int c = __ffs((int)m) - 1;
+            m &= m - 1;
+            if (!((alive >> c) & 1u)) continue;
+            if (ray[r] > ray[c]) alive &= ~(1u << r); else alive &= ~(1u << c);
+        }
+    }
+    return alive;
+}
+__device__ inline uint32_t greedy_keep_init(int V, const uint32_t* conf, const float* rowsum) {
+    uint32_t alive = (V >= 32) ? 0xffffffffu : ((1u << V) - 1u);
+    for (int r = 0; r < V; ++r) {
+        uint32_t m = conf[r];
+        while (m && ((alive >> r) & 1u)) {
+            int c = __ffs((int)m) - 1;
+            m &= m - 1;
+            if (!((alive >> c) & 1u)) continue;
+            if (rowsum[r] > rowsum[c]) alive &= ~(1u << c); else alive &= ~(1u << r);
+        }
+    }
+    return alive;
+}
+// NumPy's float32 add.reduce order over a strided 1-D row (pairwise_sum: <8 sequential, else 8 accumulators)
+template <typename Fn>
+__device__ inline float np_sum_f32(int n, Fn at) {
+    if (n < 8) {
+        float r = 0.0f;
+        for (int i = 0; i < n; ++i) r += at(i);
+        return r;
+    }
+    float r0 = at(0), r1 = at(1), r2 = at(2), r3 = at(3), r4 = at(4), r5 = at(5), r6 = at(6), r7 = at(7);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += at(i); r1 += at(i + 1); r2 += at(i + 2); r3 += at(i + 3);
+        r4 += at(i + 4); r5 += at(i + 5); r6 += at(i + 6); r7 += at(i + 7);
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += at(i);
+    return res;
+}
+
+// ---- a9: weighted DLT, construction.py:89-114 -------------------------------------------------------------------
+// smallest eigenvector of the 4x4 normal matrix by cyclic Jacobi (fully unrolled: everything stays in registers)
+__device__ inline void jacobi4_min_eigvec(double a[4][4], double out[4]) {
+    double E[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 24; ++sweep) {
+        int rotated = 0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < 4; ++q) {
+                const double apq = a[p][q];
+                if (apq != 0.0 && fabs(apq) > 1e-19 * sqrt(fabs(a[p][p] * a[q][q]))) {
+                    const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                    const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                    a[p][p] -= t * apq;
+                    a[q][q] += t * apq;
+                    a[p][q] = 0.0; a[q][p] = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (r != p && r != q) {
+                            const double arp = a[r][p], arq = a[r][q];
+                            a[r][p] = c * arp - s * arq; a[p][r] = a[r][p];
+                            a[r][q] = s * arp + c * arq; a[q][r] = a[r][q];
+                        }
+                        const double erp = E[r][p], erq = E[r][q];
+                        E[r][p] = c * erp - s * erq;
+                        E[r][q] = s * erp + c * erq;
+                    }
+                    rotated = 1;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    int k = 0;
+    double best = a[0][0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (a[i][i] < best) { best = a[i][i]; k = i; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = (k == 0) ? E[r][0] : (k == 1) ? E[r][1] : (k == 2) ? E[r][2] : E[r][3];
+}
+
+// one joint: views listed in sel_cid[0..V) with ages T -> weight w_t[T]; keep = bitmask over the V list positions;
+// pose(v) returns the (y,x,score) row of list position v for this joint
+template <typename PoseFn>
+__device__ inline void dlt_joint(const CamSet& cs, int V, const int* sel_cid, const int* sel_T, const double* w_t,
+                                 double lambda_t, uint32_t keep, PoseFn pose, double out[3]) {
+    double M[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) M[r][c] = 0.0;
+    for (int v = 0; v < V; ++v) {
+        if (!((keep >> v) & 1u)) continue;
+        const float* P = cs.P + (size_t)sel_cid[v] * 12;
+        const double* p = pose(v);
+        const int T = sel_T[v];
+        const double w = (T >= 0 && T < 4) ? w_t[T] : exp(-lambda_t * (double)T);
+        const double xy[2] = {p[1], p[0]};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double r0 = xy[h] * (double)P[8] - (double)P[4 * h + 0];
+            double r1 = xy[h] * (double)P[9] - (double)P[4 * h + 1];
+            double r2 = xy[h] * (double)P[10] - (double)P[4 * h + 2];
+            double r3 = xy[h] * (double)P[11] - (double)P[4 * h + 3];
+            const double n = sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+            r0 = w * (r0 / n); r1 = w * (r1 / n); r2 = w * (r2 / n); r3 = w * (r3 / n);
+            const double rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = a; b < 4; ++b) M[a][b] += rr[a] * rr[b];
+        }
+    }
+#pragma unroll
+    for (int a = 1; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < a; ++b) M[a][b] = M[b][a];
+    double X[4];
+    jacobi4_min_eigvec(M, X);
+    out[0] = X[0] / X[3]; out[1] = X[1] / X[3]; out[2] = X[2] / X[3];
+}
+
+// ---- a12: last sample of scipy gaussian_filter1d(mode='reflect'), IterativeTracker.py:371-383 -------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    if (n == 1) return 0;
+    const int p = 2 * n;
+    i %= p; if (i < 0) i += p;
+    return (i < n) ? i : p - 1 - i;
+}
+// seq(i): i in [0,n) sample i of one coordinate (n-1 = the new raw value); w[0..ntaps) one-sided taps
+template <typename SeqFn>
+__device__ inline double smooth_last(int n, int ntaps, const double* w, SeqFn seq) {
+    const int c = n - 1;
+    double acc = seq(c) * w[0];
+    for (int o = ntaps - 1; o >= 1; --o)
+        acc += (seq(reflect_idx(c - o, n)) + seq(reflect_idx(c + o, n))) * w[o];
+    return acc;
+}
+
+// ---- a13: float32 velocity, IterativeTracker.py:385-395 ----------------------------------------------------------
+// hist(k): coordinate value of history entry k (0 oldest .. L-1 newest), L >= 2
+template <typename HistFn>
+__device__ inline float velocity_f32(int L, HistFn hist) {
+    float acc = 0.0f;
+    int cnt = 0;
+    for (int k = L - 1; k >= 1 && cnt < 5; --k, ++cnt) {
+        const float d = (float)hist(k) - (float)hist(k - 1);
+        acc = (cnt == 0) ? d : acc + d;
+    }
+    return acc / (float)cnt;
+}
+
+// ---- a14: mean keypoint confidence, calculate.py:8-14 ------------------------------------------------------------
+__device__ inline double believe(const double* det) {
+    double s = 0.0; int n = 0;
+    for (int j = 0; j < J; ++j) { const double w = det[j * 3 + 2]; if (w >= 0.0) { s += w; ++n; } }
+    return s / (double)n;    // n == 0 -> NaN, which fails every '>' test like np.mean([]) does
+}
+
+// ---- a15: one member's contribution to Hypothesis.calculate_cost, hypothesis.py:61-66 ---------------------------
+__device__ inline double hyp_member_cost(const CamSet& cs, int cm, const double* pm, int co, const double* po, double thr) {
+    const float* F = cs.F + ((size_t)cm * cs.C + co) * 9;
+    double s = 0.0;
+    for (int j = 0; j < J; ++j) {
+        double d1, d2;
+        epi_pair_cv(F, pm[j * 3 + 1], pm[j * 3 + 0], po[j * 3 + 1], po[j * 3 + 0], d1, d2);
+        s += (d1 * pm[j * 3 + 2] + d2 * po[j * 3 + 2]) / 2.0;
+    }
+    return (s / (double)J) / thr;
+}
+
+}  // namespace pam

@@ -1,0 +1,164 @@
+// libpam_hip.so, image part of a1 (HRNetPose.predict pre/post-processing; call site /root/reference/src/ivclabpose.py:210).
+// The conv stack itself runs in PyTorch-ROCm; these two kernels bracket it.  Both are HBM-bound streaming kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pam.h"
+
+#define J PAM_J
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even; inputs are finite
+    uint32_t u = __float_as_uint(f);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+// One thread per output pixel: bilinear sample (half-pixel centres, border replicate) of the person box from the BGR
+// uint8 frame, BGR->RGB, /255, ImageNet mean/std, bf16 NHWC store (6 B per thread, contiguous across the wave).
+__global__ __launch_bounds__(256) void k_preprocess_crops(int n, const uint8_t* const* __restrict__ frames, int H, int W,
+                                                          const int* __restrict__ view_of, const float* __restrict__ boxes,
+                                                          int oh, int ow, uint16_t* __restrict__ out) {
+    const int crop = blockIdx.y;
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (crop >= n || px >= oh * ow) return;
+    const int oy = px / ow, ox = px % ow;
+    const uint8_t* __restrict__ img = frames[view_of[crop]];
+    const float bx = boxes[crop * 4 + 0], by = boxes[crop * 4 + 1], bw = boxes[crop * 4 + 2], bh = boxes[crop * 4 + 3];
+    float sx = bx + (ox + 0.5f) * (bw / (float)ow) - 0.5f;
+    float sy = by + (oy + 0.5f) * (bh / (float)oh) - 0.5f;
+    sx = fminf(fmaxf(sx, 0.0f), (float)(W - 1));
+    sy = fminf(fmaxf(sy, 0.0f), (float)(H - 1));
+    const int x0 = (int)sx, y0 = (int)sy;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float fx = sx - (float)x0, fy = sy - (float)y0;
+    const uint8_t* r0 = img + ((size_t)y0 * W) * 3;
+    const uint8_t* r1 = img + ((size_t)y1 * W) * 3;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f};
+    uint16_t o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {          // c indexes RGB; source is BGR
+        const int sc = 2 - c;
+        const float a = (float)r0[x0 * 3 + sc], b = (float)r0[x1 * 3 + sc];
+        const float cc = (float)r1[x0 * 3 + sc], d = (float)r1[x1 * 3 + sc];
+        const float top = a + (b - a) * fx, bot = cc + (d - cc) * fx;
+        const float v = (top + (bot - top) * fy) * (1.0f / 255.0f);
+        o[c] = f32_to_bf16((v - mean[c]) * istd[c]);
+    }
+    uint16_t* dst = out + (((size_t)crop * oh + oy) * ow + ox) * 3;
+    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+}
+
+struct Best { float v; int i; };
+__device__ __forceinline__ Best better(Best a, Best b) {    // larger value wins; ties -> smaller flat index (np.argmax)
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ Best wave_argmax(Best x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Best o; o.v = __shfl_xor(x.v, off, 64); o.i = __shfl_xor(x.i, off, 64);
+        x = better(x, o);
+    }
+    return x;
+}
+__device__ __forceinline__ void write_keypoint(int j, Best b, int hm_h, int hm_w, const float* box, double* det_row, float* kp_row) {
+    const int py = b.i / hm_w, pxx = b.i % hm_w;
+    // upstream SimpleHRNet.predict: pt / (res // 4) * box extent + box origin, stored float32
+    const float y = (float)((double)py / (double)hm_h * (double)box[3] + (double)box[1]);
+    const float x = (float)((double)pxx / (double)hm_w * (double)box[2] + (double)box[0]);
+    det_row[j * 3 + 0] = (double)y; det_row[j * 3 + 1] = (double)x; det_row[j * 3 + 2] = (double)b.v;
+    if (kp_row) { kp_row[j * 3 + 0] = x; kp_row[j * 3 + 1] = y; kp_row[j * 3 + 2] = b.v; }
+}
+
+// NHWC heat-maps (n, H, W, 17) float32: one workgroup per person.  Pixel tiles of 256 x 17 floats are staged through LDS
+// with coalesced 16-byte loads; each lane then owns one pixel and reads its 17 values at stride 17 words (odd stride:
+// conflict-free), keeping 17 running (max, index) pairs in registers.
+#define TILE_PX 256
+__global__ __launch_bounds__(256) void k_decode_nhwc(int n, const float* __restrict__ hm, int hm_h, int hm_w,
+                                                     const int* __restrict__ view_of, const int* __restrict__ slot_of,
+                                                     const float* __restrict__ boxes, int max_dets, double* __restrict__ det,
+                                                     float* __restrict__ kp) {
+    __shared__ __attribute__((aligned(16))) float tile[TILE_PX * J];
+    __shared__ Best red[4][J];
+    const int crop = blockIdx.x, tid = threadIdx.x;
+    const int HW = hm_h * hm_w;
+    const float* src = hm + (size_t)crop * HW * J;
+    Best best[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { best[j].v = -__builtin_huge_valf(); best[j].i = 0x7fffffff; }
+    for (int base = 0; base < HW; base += TILE_PX) {
+        const int npx = min(TILE_PX, HW - base);
+        const int nfl = npx * J;
+        const float* g = src + (size_t)base * J;
+        if ((nfl & 3) == 0 && (((uintptr_t)g & 15) == 0)) {
+            const float4* g4 = (const float4*)g; float4* t4 = (float4*)tile;
+            for (int e = tid; e < nfl / 4; e += 256) t4[e] = g4[e];
+        } else {
+            for (int e = tid; e < nfl; e += 256) tile[e] = g[e];
+        }
+        __syncthreads();
+        if (tid < npx) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float v = tile[tid * J + j];
+                if (v > best[j].v) { best[j].v = v; best[j].i = base + tid; }   // strictly greater: earlier index wins ties
+            }
+        }
+        __syncthreads();
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        Best b = wave_argmax(best[j]);
+        if (lane == 0) red[wave][j] = b;
+    }
+    __syncthreads();
+    if (tid < J) {
+        Best b = better(better(red[0][tid], red[1][tid]), better(red[2][tid], red[3][tid]));
+        double* row = det + ((size_t)view_of[crop] * max_dets + slot_of[crop]) * J * 3;
+        write_keypoint(tid, b, hm_h, hm_w, boxes + crop * 4, row, kp ? kp + (size_t)crop * J * 3 : nullptr);
+    }
+}
+
+// NCHW heat-maps (n, 17, H, W): one workgroup per (person, joint), plain coalesced scan.
+__global__ __launch_bounds__(256) void k_decode_nchw(int n, const float* __restrict__ hm, int hm_h, int hm_w,
+                                                     const int* __restrict__ view_of, const int* __restrict__ slot_of,
+                                                     const float* __restrict__ boxes, int max_dets, double* __restrict__ det,
+                                                     float* __restrict__ kp) {
+    __shared__ Best red[4];
+    const int crop = blockIdx.x / J, j = blockIdx.x % J, tid = threadIdx.x;
+    const int HW = hm_h * hm_w;
+    const float* src = hm + ((size_t)crop * J + j) * HW;
+    Best b; b.v = -__builtin_huge_valf(); b.i = 0x7fffffff;
+    for (int e = tid; e < HW; e += 256) { const float v = src[e]; if (v > b.v) { b.v = v; b.i = e; } }
+    b = wave_argmax(b);
+    if ((tid & 63) == 0) red[tid >> 6] = b;
+    __syncthreads();
+    if (tid == 0) {
+        b = better(better(red[0], red[1]), better(red[2], red[3]));
+        double* row = det + ((size_t)view_of[crop] * max_dets + slot_of[crop]) * J * 3;
+        write_keypoint(j, b, hm_h, hm_w, boxes + crop * 4, row, kp ? kp + (size_t)crop * J * 3 : nullptr);
+    }
+}
+
+extern "C" int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames, int frame_h, int frame_w,
+                                    const int32_t* dev_view_of, const float* dev_boxes, int out_h, int out_w,
+                                    void* dev_out_bf16) {
+    if (n < 0 || !dev_frames || !dev_view_of || !dev_boxes || !dev_out_bf16 || out_h <= 0 || out_w <= 0) return PAM_E_ARG;
+    if (n == 0) return PAM_OK;
+    dim3 grid((out_h * out_w + 255) / 256, n);
+    hipLaunchKernelGGL(k_preprocess_crops, grid, dim3(256), 0, (hipStream_t)stream, n, (const uint8_t* const*)dev_frames,
+                       frame_h, frame_w, dev_view_of, dev_boxes, out_h, out_w, (uint16_t*)dev_out_bf16);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+extern "C" int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw, int hm_h, int hm_w,
+                                   const int32_t* dev_view_of, const int32_t* dev_slot_of, const float* dev_boxes,
+                                   int max_dets, double* dev_det, float* dev_kp_xyc) {
+    if (n < 0 || !dev_heatmaps || !dev_view_of || !dev_slot_of || !dev_boxes || !dev_det || hm_h <= 0 || hm_w <= 0) return PAM_E_ARG;
+    if (n == 0) return PAM_OK;
+    if (nchw)
+        hipLaunchKernelGGL(k_decode_nchw, dim3(n * J), dim3(256), 0, (hipStream_t)stream, n, dev_heatmaps, hm_h, hm_w,
+                           dev_view_of, dev_slot_of, dev_boxes, max_dets, dev_det, dev_kp_xyc);
+    else
+        hipLaunchKernelGGL(k_decode_nhwc, dim3(n), dim3(256), 0, (hipStream_t)stream, n, dev_heatmaps, hm_h, hm_w,
+                           dev_view_of, dev_slot_of, dev_boxes, max_dets, dev_det, dev_kp_xyc);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}

@@ -1,0 +1,192 @@
+"""GPU parity: the HIP path (through the C ABI / ctypes) against the golden vectors captured from the reference and
+against the CPU oracle on seeded inputs.  Bar: view / person assignment indices bit-exact; 3D joints <= 1e-3 m
+(north_star), tested here at 1e-6 m; intermediate float64 quantities <= 1e-9 relative."""
+import numpy as np
+import pytest
+
+import golden_io as G
+from trace_driver import run_trace
+from oracle import cpu_ref as O
+from pam import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from pam import _lib
+    return _lib
+
+
+def _handle(lib, size, **kw):
+    c = G.cameras(size)
+    cfg = dict(synth.MATCHER_CFG[synth.SIZE_TO_DATASET[size]])
+    conf = cfg.pop('CONF_THRESHOLD')
+    h = lib.Handle(len(c['P32']), lib.make_params(cfg, conf), **kw)
+    h.set_cameras(c['P32'], c['F'], c['RK_INV'], c['position'])
+    return h, cfg
+
+
+def _mask(keep_idx):
+    m = 0
+    for k in keep_idx:
+        m |= 1 << int(k)
+    return m
+
+
+@pytest.mark.parametrize('size', G.SIZES)
+def test_ops_vs_golden(lib, size):
+    h, cfg = _handle(lib, size)
+    ops = G.ops(size)
+    for r in ops['project']:
+        np.testing.assert_allclose(h.op_project(int(r['cid']), r['pts']), r['out'], rtol=TOL, atol=TOL)
+    for r in ops['assoc']:
+        aff = h.op_track_affinity(int(r['cid']), r['tracks_pose'], r['dt'], r['dets'])
+        np.testing.assert_allclose(aff, r['affinity'], rtol=TOL, atol=TOL)
+        rows, cols = h.op_lsap(-r['affinity'])
+        assert np.array_equal(rows, r['rows']) and np.array_equal(cols, r['cols'])
+        rows, cols = h.op_lsap(-aff)            # device affinity -> same assignment
+        assert np.array_equal(rows, r['rows']) and np.array_equal(cols, r['cols'])
+    for r in ops['lsap_init']:
+        rows, cols = h.op_lsap(r['cost'])
+        assert np.array_equal(rows, r['rows']) and np.array_equal(cols, r['cols'])
+    for r in ops['epi_par']:
+        np.testing.assert_allclose(h.op_epi_dist(r['cids'], r['pose_mat']), r['dist'], rtol=TOL, atol=TOL)
+    for r in ops['epi_distance']:
+        np.testing.assert_allclose(h.op_epi_pair(int(r['c1']), r['p1'], int(r['c2']), r['p2']), r['out'], rtol=TOL, atol=TOL)
+    for r in ops['epi_loop']:
+        d = h.op_epi_dist_init(r['cids'], r['pose_mat'])
+        np.testing.assert_allclose(d, r['dist'], rtol=1e-6, atol=1e-6)
+    for r in ops['greedy_update']:
+        k = h.op_greedy('update', r['cids'], r['aff'], r['pose'][:, 0, :], r['next_pose'])
+        assert k == _mask(r['matched'])
+    for r in ops['greedy_init']:
+        k = h.op_greedy('init', r['cids'], r['aff'])
+        assert k == _mask(r['matched'])
+    for op in ('dlt_update', 'dlt_init'):
+        for r in ops[op]:
+            V = len(r['cids'])
+            masks = [_mask([v for v in range(V) if r['remains'][j, 2 * v] == 1]) for j in range(17)]
+            out = h.op_dlt(r['cids'], r['Ts'], r['pose_mat'], masks, r['next_pose'])
+            np.testing.assert_allclose(out, r['out'], rtol=0, atol=1e-7)
+    for r in ops['hyp_cost']:
+        c, veto = h.op_hyp_cost(r['cids'], r['poses'], int(r['o_cid']), r['o_pose'])
+        assert abs(c - float(r['cost'])) <= TOL * max(1.0, abs(float(r['cost'])))
+        assert int(veto) == int(r['veto'])
+    for r in ops['smooth']:
+        np.testing.assert_allclose(h.op_smooth(r['hist'], r['raw']), r['out'], rtol=1e-12, atol=1e-12)
+    for r in ops['motion']:
+        assert np.array_equal(h.op_velocity(r['hist']), r['vel'])
+    h.close()
+
+
+def test_lsap_fuzz_vs_oracle(lib):
+    h, _ = _handle(lib, 'S1')
+    rng = np.random.default_rng(3)
+    for it in range(120):
+        n, m = rng.integers(1, 12, size=2)
+        kind = it % 3
+        if kind == 0:
+            cost = rng.normal(size=(n, m))
+        elif kind == 1:
+            cost = rng.integers(0, 3, size=(n, m)).astype(float)
+        else:
+            cost = np.zeros((n, m))
+            for _ in range(min(n, m)):
+                cost[rng.integers(n), rng.integers(m)] = -rng.uniform(0.1, 1)
+        r0, c0 = O.lsap(cost)
+        r1, c1 = h.op_lsap(cost)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), cost
+    r, c = h.op_lsap(np.zeros((0, 3)))
+    assert len(r) == 0
+    h.close()
+
+
+def test_dlt_vs_oracle_random_masks(lib):
+    """Random view subsets / ages, including degenerate 2-view joints: device Jacobi vs LAPACK SVD (oracle)."""
+    h, cfg = _handle(lib, 'S4')
+    c = G.cameras('S4')
+    cams = O.cameras_from_arrays(c['P32'], c['K32'], c['RT32'], c['F'], c['RK_INV'], c['position'])
+    seq = synth.make_sequence('S4', n_frames=2, seed=5, outlier_p=0.0)
+    rng = np.random.default_rng(5)
+    for trial in range(10):
+        V = int(rng.integers(2, 32))
+        cids = rng.permutation(31)[:V]
+        person = 0
+        pm = np.stack([seq['frames'][1][cid][person][:, [1, 0, 2]] for cid in cids])
+        # undo the per-view shuffle: use GT projection instead so all rows belong to one person
+        X = seq['gt3d'][1][1]
+        for q, cid in enumerate(cids):
+            hm = np.concatenate([X, np.ones((17, 1))], 1) @ c['P'][cid].T
+            xy = hm[:, :2] / hm[:, 2:3] + rng.normal(0, 1.5, (17, 2))
+            pm[q, :, 0], pm[q, :, 1] = xy[:, 1], xy[:, 0]
+        Ts = rng.integers(0, 4, size=V)
+        nviews = np.zeros(17, dtype=np.int64); mask = np.zeros((17, 2 * V), dtype=np.int64); masks = []
+        for j in range(17):
+            k = int(rng.integers(2, V + 1))
+            keep = np.sort(rng.permutation(V)[:k])
+            nviews[j] = k
+            mask[j, np.repeat(keep * 2, 2) + np.tile([0, 1], k)] = 1
+            masks.append(_mask(keep))
+        cs = [cams[i] for i in cids]
+        exp = O.dlt_solve(O.dlt_rows(cs, pm, Ts, cfg['LAMBDA_T']), mask, nviews, np.zeros((17, 3)))
+        got = h.op_dlt(cids, Ts, pm, masks, np.zeros((17, 3)))
+        np.testing.assert_allclose(got, exp, rtol=0, atol=1e-7)
+    h.close()
+
+
+@pytest.mark.parametrize('size', G.SIZES)
+def test_trace_vs_golden(size):
+    """Whole sequences through the drop-in facade: ids, view sets, joints_views, camera ids bit-exact; 3D <= 1e-6 m;
+    tracker state (hits / age / order / velocity) identical to the reference's after every frame."""
+    from pam.ivclabpose import ivclabpose
+
+    def factory(cfg, conf):
+        return ivclabpose(person_detector={'NAME': ''}, pose_detector=None,
+                          person_matcher=dict(cfg, NAME='Iterative'), conf_threshold=conf)
+    nf = 0
+    for t, tr, model in run_trace(size, factory, atol3d=1e-6):
+        k = 'f%d.st.' % t
+        trs = model.tracker.tracks
+        assert model.tracker.last['status'] == 0
+        assert [x.track_id for x in trs] == tr[k + 'ids'].tolist(), (size, t)
+        assert [x.state for x in trs] == tr[k + 'state'].tolist()
+        assert [x.hits for x in trs] == tr[k + 'hits'].tolist()
+        assert [x.age for x in trs] == tr[k + 'age'].tolist()
+        assert [x.time_since_update for x in trs] == tr[k + 'tsu'].tolist()
+        assert [x.nhist for x in trs] == tr[k + 'nhist'].tolist()
+        assert [x.last_time for x in trs] == tr[k + 'last_time'].tolist()
+        for i, x in enumerate(trs):
+            assert x.order == [int(c) for c in tr[k + 'p2d_order'][i] if c >= 0]
+            np.testing.assert_allclose(x.pose3d, tr[k + 'last_pose'][i], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(x.velocity_3d, tr[k + 'velocity'][i], rtol=0, atol=1e-6)
+        nf += 1
+    assert nf > 20
+
+
+def test_batched_scenes_match_single(lib):
+    """n_scenes independent trackers in one launch give, per scene, what a single-scene handle gives."""
+    S = 3
+    seqs = [synth.make_sequence('S2', n_frames=40, seed=10 + s) for s in range(S)]
+    calib = seqs[0]['calib']
+    cams = O.make_cameras(calib)
+    cfg = dict(synth.MATCHER_CFG['Shelf']); conf = cfg.pop('CONF_THRESHOLD')
+    prm = lib.make_params(cfg, conf)
+    args = (np.stack([c.P for c in cams]), np.stack([c.F for c in cams]), np.stack([c.RK_INV for c in cams]),
+            np.stack([c.position for c in cams]))
+    hb = lib.Handle(5, prm, max_dets=8, max_tracks=16, n_scenes=S); hb.set_cameras(*args)
+    singles = []
+    for s in range(S):
+        hs = lib.Handle(5, prm, max_dets=8, max_tracks=16, n_scenes=1); hs.set_cameras(*args); singles.append(hs)
+    packed = [synth.pack_frames(q['frames'], 8) for q in seqs]
+    for t in range(40):
+        nd = np.stack([p[0][t] for p in packed]); dd = np.stack([p[1][t] for p in packed])
+        oi, od = hb.frame(t, nd, dd)
+        for s in range(S):
+            si, sd = singles[s].frame(t, nd[s:s + 1], dd[s:s + 1])
+            assert np.array_equal(oi[s], si[0])
+            assert np.array_equal(od[s][4:], sd[0][4:])      # [0:4] are clocks
+    for hs in singles:
+        hs.close()
+    hb.close()
