@@ -246,33 +246,49 @@ __device__ inline float np_sum_f32(int n, Fn at) {
 }
 
 // ---- a9: weighted DLT, construction.py:89-114 -------------------------------------------------------------------
-// smallest eigenvector of the 4x4 normal matrix by cyclic Jacobi (fully unrolled: everything stays in registers)
-__device__ inline void jacobi4_min_eigvec(double a[4][4], double out[4]) {
+// Null vector of the stacked (2k x 4) system WITHOUT forming the normal matrix: rows are folded one at a time into a
+// 4x4 upper-triangular R by Givens rotations (row-wise QR), then the right singular vector of R's smallest singular
+// value comes from one-sided (Hestenes) Jacobi on R's columns.  Backward stable like the LAPACK SVD the reference calls
+// (rows weighted by exp(-lambda_t*T) ~ 3e-7 would lose half the digits in A^T A).  Fully unrolled: registers only.
+__device__ __forceinline__ void givens_fold_row(double R[4][4], double r[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double b = r[k];
+        if (b != 0.0) {
+            const double a = R[k][k];
+            const double h = sqrt(a * a + b * b);
+            const double c = a / h, s = b / h;
+            R[k][k] = h;
+#pragma unroll
+            for (int m = k + 1; m < 4; ++m) {
+                const double t = R[k][m];
+                R[k][m] = c * t + s * r[m];
+                r[m] = c * r[m] - s * t;
+            }
+        }
+    }
+}
+__device__ inline void min_right_singular_vector(double W[4][4], double out[4]) {
     double E[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-    for (int sweep = 0; sweep < 24; ++sweep) {
+    for (int sweep = 0; sweep < 30; ++sweep) {
         int rotated = 0;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
             for (int q = p + 1; q < 4; ++q) {
-                const double apq = a[p][q];
-                if (apq != 0.0 && fabs(apq) > 1e-19 * sqrt(fabs(a[p][p] * a[q][q]))) {
-                    const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
-                    const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                    a[p][p] -= t * apq;
-                    a[q][q] += t * apq;
-                    a[p][q] = 0.0; a[q][p] = 0.0;
+                double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (r != p && r != q) {
-                            const double arp = a[r][p], arq = a[r][q];
-                            a[r][p] = c * arp - s * arq; a[p][r] = a[r][p];
-                            a[r][q] = s * arp + c * arq; a[q][r] = a[r][q];
-                        }
-                        const double erp = E[r][p], erq = E[r][q];
-                        E[r][p] = c * erp - s * erq;
-                        E[r][q] = s * erp + c * erq;
+                for (int i = 0; i < 4; ++i) { al += W[i][p] * W[i][p]; be += W[i][q] * W[i][q]; ga += W[i][p] * W[i][q]; }
+                if (ga != 0.0 && fabs(ga) > 1e-16 * sqrt(al * be)) {
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double wp = W[i][p], wq = W[i][q];
+                        W[i][p] = c * wp - s * wq; W[i][q] = s * wp + c * wq;
+                        const double ep = E[i][p], eq = E[i][q];
+                        E[i][p] = c * ep - s * eq; E[i][q] = s * ep + c * eq;
                     }
                     rotated = 1;
                 }
@@ -280,10 +296,13 @@ __device__ inline void jacobi4_min_eigvec(double a[4][4], double out[4]) {
         }
         if (!rotated) break;
     }
-    int k = 0;
-    double best = a[0][0];
+    double n[4];
 #pragma unroll
-    for (int i = 1; i < 4; ++i) if (a[i][i] < best) { best = a[i][i]; k = i; }
+    for (int c = 0; c < 4; ++c) n[c] = W[0][c] * W[0][c] + W[1][c] * W[1][c] + W[2][c] * W[2][c] + W[3][c] * W[3][c];
+    int k = 0;
+    double best = n[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) if (n[i] < best) { best = n[i]; k = i; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[r] = (k == 0) ? E[r][0] : (k == 1) ? E[r][1] : (k == 2) ? E[r][2] : E[r][3];
 }
@@ -293,11 +312,11 @@ __device__ inline void jacobi4_min_eigvec(double a[4][4], double out[4]) {
 template <typename PoseFn>
 __device__ inline void dlt_joint(const CamSet& cs, int V, const int* sel_cid, const int* sel_T, const double* w_t,
                                  double lambda_t, uint32_t keep, PoseFn pose, double out[3]) {
-    double M[4][4];
+    double R[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) M[r][c] = 0.0;
+        for (int c = 0; c < 4; ++c) R[r][c] = 0.0;
     for (int v = 0; v < V; ++v) {
         if (!((keep >> v) & 1u)) continue;
         const float* P = cs.P + (size_t)sel_cid[v] * 12;
@@ -312,20 +331,12 @@ __device__ inline void dlt_joint(const CamSet& cs, int V, const int* sel_cid, co
             double r2 = xy[h] * (double)P[10] - (double)P[4 * h + 2];
             double r3 = xy[h] * (double)P[11] - (double)P[4 * h + 3];
             const double n = sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
-            r0 = w * (r0 / n); r1 = w * (r1 / n); r2 = w * (r2 / n); r3 = w * (r3 / n);
-            const double rr[4] = {r0, r1, r2, r3};
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = a; b < 4; ++b) M[a][b] += rr[a] * rr[b];
+            double rr[4] = {w * (r0 / n), w * (r1 / n), w * (r2 / n), w * (r3 / n)};
+            givens_fold_row(R, rr);
         }
     }
-#pragma unroll
-    for (int a = 1; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < a; ++b) M[a][b] = M[b][a];
     double X[4];
-    jacobi4_min_eigvec(M, X);
+    min_right_singular_vector(R, X);
     out[0] = X[0] / X[3]; out[1] = X[1] / X[3]; out[2] = X[2] / X[3];
 }
 
