@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Headline benchmark: end-to-end multi-view frames/s of the per-frame hot path on synthetic Shelf-like frames
+(5 cameras, 1032x776, 4 persons -> 20 person crops per frame):
+
+    crop/resize/normalise (HIP) -> HRNet-W48 384x288 conv stack (PyTorch-ROCm bf16, hipGraph) -> heat-map decode (HIP)
+    -> [one all-gather of per-view keypoints when views are sharded over ranks] -> fused tracker frame kernel (HIP):
+    association + part-aware epipolar view filter + weighted DLT + smoothing + hypothesis initialisation.
+
+A step = one frame.  All inputs (frames, person boxes, synthetic 2D keypoints) are resident in HBM before the timed
+region.  As SURVEY 8d prescribes, HRNet runs on real shapes with seeded random weights (no checkpoints offline) and its
+decode output is computed but the tracker consumes the seeded synthetic keypoints, so association behaves realistically.
+One process per GPU (torch.distributed / RCCL); with --gpus N the camera views are partitioned over the N ranks.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md 'Measurement' for how roofline / cpu_baseline are derived."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0               # HBM3E spec, same table
+
+
+def algorithmic_bytes_per_frame(C, P, T, V, L, J=17):
+    """SURVEY 8d matching-path bytes: detections in + per-track state read/write + outputs."""
+    det = C * P * J * 3 * 8
+    per_track = (L + 2) * J * 3 * 8 + V * J * 3 * 8
+    out = T * J * 3 * 8 + C * P * 4 + T * J * 4
+    return det + T * per_track + out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='S2', choices=['S1', 'S2', 'S3', 'S4'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-batched', action='store_true')
+    ap.add_argument('--batched-scenes', type=int, default=2048)
+    ap.add_argument('--no-graph', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda:%d' % local_rank))
+    assert args.gpus == world, '--gpus must equal the number of launched ranks (use torch.distributed.run for N>1)'
+    dev = torch.device('cuda:%d' % local_rank)
+    torch.cuda.set_device(dev)
+
+    import pam  # noqa: F401
+    from pam import synth, hrnet as hrnet_mod
+    from pam.ivclabpose import Camera, fundamental_matrices
+    from pam.pipeline import FramePipeline
+
+    size = args.workload
+    meta = synth.SIZES[size]
+    C, P, fw, fh = meta['C'], meta['P'], meta['w'], meta['h']
+    K, W = args.steps, args.warmup
+    nF = K + W
+    seq = synth.make_sequence(size, n_frames=nF, seed=0)
+    dataset = synth.SIZE_TO_DATASET[size]
+    cfg = dict(synth.MATCHER_CFG[dataset]); conf = cfg.pop('CONF_THRESHOLD')
+    P32 = seq['calib']['P'].astype(np.float32); K32 = seq['calib']['K'].astype(np.float32)
+    RT32 = seq['calib']['RT'].astype(np.float32)
+    Fm = fundamental_matrices(K32, RT32)
+    cams = [Camera(j, P32[j], K32[j], RT32[j], Fm[j], w=fw, h=fh) for j in range(C)]
+    max_dets = 8
+    pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
+                         rank=rank, use_graph=not args.no_graph)
+    mine = pipe.mine
+    kl = len(mine)
+
+    # ---- inputs resident in HBM ----------------------------------------------------------------------------------------
+    g = torch.Generator().manual_seed(1234 + rank)
+    frames_dev = [torch.randint(0, 256, (fh, fw, 3), dtype=torch.uint8, generator=g).to(dev) for _ in mine]
+    frame_ptrs = torch.tensor([f.data_ptr() for f in frames_dev] or [0], dtype=torch.int64, device=dev)
+    n_det_all, det_all = synth.pack_frames(seq['frames'], max_dets)            # (F,C), (F,C,maxd,17,3) (y,x,s)
+    per_frame = []
+    for t in range(nF):
+        vl, sl, bx = [], [], []
+        for li, v in enumerate(mine):
+            for s, kp in enumerate(seq['frames'][t][v]):
+                x0, y0, x1, y1 = kp[:, 0].min(), kp[:, 1].min(), kp[:, 0].max(), kp[:, 1].max()
+                vl.append(li); sl.append(s)
+                bx.append([x0 - 0.125 * (x1 - x0), y0 - 0.125 * (y1 - y0), 1.25 * (x1 - x0), 1.25 * (y1 - y0)])
+        per_frame.append((torch.tensor(vl, dtype=torch.int32, device=dev), torch.tensor(sl, dtype=torch.int32, device=dev),
+                          torch.tensor(bx, dtype=torch.float32, device=dev).reshape(-1, 4),
+                          torch.tensor(n_det_all[t, mine], dtype=torch.int32, device=dev),
+                          torch.tensor(det_all[t][mine], dtype=torch.float64, device=dev).reshape(kl, max_dets, 17, 3)))
+    crops_per_frame = [int(sum(len(seq['frames'][t][v]) for v in range(C))) for t in range(nF)]
+    local_crops = [int(p[0].numel()) for p in per_frame]
+    torch.cuda.synchronize()
+
+    def step(t, ev=None):
+        vl, sl, bx, nd, dd = per_frame[t]
+        pipe.pose_step(frame_ptrs, vl, sl, bx, ev)
+        pipe.track_step(t, nd, dd)
+
+    # ---- warm-up (includes hipGraph capture of every crop count that occurs) -------------------------------------------
+    for n in sorted(set(local_crops)):
+        if n > 0 and pipe.net is not None:
+            x = pipe.net.input_buffer(n)
+            pipe.net.heatmaps(x)
+    for t in range(W):
+        step(t)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    # ---- timed region: exactly K frames -----------------------------------------------------------------------------
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(W + i, evs[i])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final = pipe.results()
+
+    # dominant kernel: the HRNet conv stack (one hipGraph replay per frame), HIP events on the launch stream
+    flops_crop = hrnet_mod.count_flops()
+    hr_ms = [a.elapsed_time(b) for (a, b), n in zip(evs, local_crops[W:]) if n > 0]
+    hr_fl = [flops_crop * n for n in local_crops[W:] if n > 0]
+    if hr_ms:
+        avg_ms = float(np.mean(hr_ms))
+        achieved = float(np.sum(hr_fl) / (np.sum(hr_ms) * 1e-3) / 1e12)
+    else:
+        avg_ms, achieved = 0.0, 0.0
+
+    out = None
+    if rank == 0:
+        fps = K / elapsed
+        out = {
+            'metric': 'multi-view frames/sec (end-to-end: HRNet-W48 2D pose + part-aware cross-view matching + DLT tracking)',
+            'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'bf16 convs / f64 matching', 'data': 'synthetic',
+            'config': {'workload': 'Shelf-like %s: %d cams %dx%d, %d persons, %d crops/frame 384x288, 17 joints'
+                                   % (size, C, fw, fh, P, int(np.median(crops_per_frame))),
+                       'views_per_rank': [len(p) for p in pipe.gather.parts], 'tracker': 'fused HIP frame kernel (f64)',
+                       'hrnet_weights': pipe.net.weights if pipe.net else None, 'exchange': 'all_gather per frame' if world > 1 else 'none'},
+            'roofline': {'kernel': 'HRNet-W48 conv stack (hipGraph replay, %d crops)' % int(np.median([n for n in local_crops[W:] if n > 0] or [0])),
+                         'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': avg_ms,
+                         'flops_per_crop': flops_crop},
+            'final_tracks': [t['track_id'] for t in final['tracks'] if t['emitted']],
+        }
+
+    # ---- secondary kernels (own HIP kernels), measured after the timed region -----------------------------------------
+    if rank == 0:
+        def ev_time(fn, iters=50):
+            fn(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / iters * 1e-3
+        tq = W + K - 1
+        vl, sl, bx, nd, dd = per_frame[tq]
+        n = int(vl.numel())
+        kern = []
+        if n > 0 and pipe.net is not None:
+            x = pipe.net.input_buffer(n)
+            s = ev_time(lambda: pipe.net.preprocess(frame_ptrs, fh, fw, vl, bx, x))
+            by = float((bx[:, 2] * bx[:, 3]).sum().item()) * 3 + n * 3 * 384 * 288 * 2
+            kern.append({'kernel': 'k_preprocess_crops', 'bound': 'hbm', 'achieved': by / s / 1e9, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': by / s / 1e9 / HBM_PEAK_GBS, 'us': s * 1e6, 'bytes': by})
+            hm = pipe.net.heatmaps(x)
+            s = ev_time(lambda: pipe.net.decode(hm, vl, sl, bx, pipe.det_local))
+            by = n * (17 * 96 * 72 * 4 + 17 * 3 * 8)
+            kern.append({'kernel': 'k_decode_nhwc', 'bound': 'hbm', 'achieved': by / s / 1e9, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': by / s / 1e9 / HBM_PEAK_GBS, 'us': s * 1e6, 'bytes': by})
+        out['kernels'] = kern
+
+        if not args.no_batched:
+            out['tracker_batched'] = batched_tracker(torch, synth, cams, cfg, conf, size, args.batched_scenes, dev)
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame)
+            out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def batched_tracker(torch, synth, cams, cfg, conf, size, B, dev, n_frames=40, distinct=8):
+    """B independent scenes per launch of the fused tracker kernel: the regime where it is a streaming HBM kernel."""
+    from pam import _lib
+    C = len(cams)
+    max_dets = 8
+    prm = _lib.make_params(cfg, conf)
+    h = _lib.Handle(C, prm, max_dets=max_dets, max_tracks=16, n_scenes=B, device=dev.index)
+    h.set_cameras(np.stack([c.P for c in cams]), np.stack([c.F for c in cams]), np.stack([c.RK_INV for c in cams]),
+                  np.stack([c.position for c in cams]))
+    packs = [synth.pack_frames(synth.make_sequence(size, n_frames=n_frames, seed=100 + s)['frames'], max_dets) for s in range(distinct)]
+    reps = (B + distinct - 1) // distinct
+    nd = [torch.tensor(np.tile(np.stack([p[0][t] for p in packs]), (reps, 1))[:B], dtype=torch.int32, device=dev) for t in range(n_frames)]
+    dd = [torch.tensor(np.tile(np.stack([p[1][t] for p in packs]), (reps, 1, 1, 1, 1))[:B], dtype=torch.float64, device=dev) for t in range(n_frames)]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    warm = 10
+    for t in range(warm):
+        h.frame_dev(st, t, nd[t].data_ptr(), dd[t].data_ptr())
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for t in range(warm, n_frames):
+        h.frame_dev(st, t, nd[t].data_ptr(), dd[t].data_ptr())
+    b.record(); torch.cuda.synchronize()
+    sec = a.elapsed_time(b) * 1e-3 / (n_frames - warm)
+    oi, od = h.fetch(st); h.sync(st)
+    rec = h.decode(0)
+    T = rec['n_tracks']
+    V = int(np.mean([t['V'] for t in rec['tracks']])) if T else 0
+    by = algorithmic_bytes_per_frame(C, synth.SIZES[size]['P'], T, V, 11) * B
+    status = int(max(oi[:, 1]))
+    h.close()
+    return {'kernel': 'k_frame', 'scenes': B, 'us_per_launch': sec * 1e6, 'scene_frames_per_s': B / sec,
+            'bound': 'hbm', 'achieved': by / sec / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': by / sec / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_scene_frame': by // B, 'status': status}
+
+
+def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
+    """The CPU path timed on this box's host cores, bounded sample: (i) the oracle (NumPy restatement of the reference's
+    matching path, single thread like the reference) over the first frames; (ii) the same HRNet-W48 module in fp32 on CPU
+    PyTorch with all cores, a few crops, scaled to the workload's crops/frame.  end-to-end fps = 1/(t_hrnet + t_match)."""
+    from oracle import cpu_ref as O
+    ncores = os.cpu_count()
+    ref = O.OracleIvclabpose(cfg, conf)
+    ref.GetCameraParameters(seq['calib'], F=Fm)
+    n_match = min(len(seq['frames']), 100)
+    packed = [synth.to_dump_results(v) for v in seq['frames'][:n_match]]
+    t0 = time.perf_counter()
+    for t, (pbl, dr) in enumerate(packed):
+        ref.PersonTrack_Project3DPose(t, pbl, dr, 'SVD')
+    t_match = (time.perf_counter() - t0) / n_match
+    torch.set_num_threads(ncores)
+    model = hrnet_mod.fold_batchnorm(hrnet_mod.init_random(hrnet_mod.PoseHighResolutionNet())).eval()
+    n_crops = 2
+    x = torch.randn(n_crops, 3, 384, 288)
+    with torch.no_grad():
+        model(x[:1])
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 2 or (time.perf_counter() - t0 < 8.0 and reps < 6):
+            model(x); reps += 1
+        t_crop = (time.perf_counter() - t0) / (reps * n_crops)
+    crops = float(np.median(crops_per_frame))
+    t_hr = t_crop * crops
+    return {'value': 1.0 / (t_hr + t_match), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
+            'sample': 'oracle tracker (1 thread) over %d frames: %.2f ms/frame; HRNet-W48 fp32 CPU PyTorch (%d threads) %d reps x %d crops: '
+                      '%.3f s/crop x %d crops/frame' % (n_match, t_match * 1e3, ncores, reps, n_crops, t_crop, int(crops)),
+            'match_ms_per_frame': t_match * 1e3, 'hrnet_s_per_frame': t_hr}
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,407 @@
+"""HRNet-W48 top-down 2D pose (a1): the ``HRNetPose(...).predict(...)`` seam of the reference
+(/root/reference/src/ivclabpose.py:125-134,210; the backend itself is git-ignored there).
+
+The conv stack is a plain PyTorch-ROCm module (public HRNet architecture, official state-dict key layout so
+``pose_hrnet_w48_384x288.pth`` loads), run in bf16 channels-last with BatchNorm folded and replayed from a hipGraph.
+Crop / resize / normalise and the heat-map arg-max decode are HIP kernels of libpam_hip.so (csrc/pam_image.hip).
+Parity with the authors' modified backend is UNPINNED (no source, weights or tests in the reference): decode follows
+upstream simple-HRNet (hard arg-max, linear map through the box)."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as Fnn
+
+from . import _lib
+
+BN_EPS = 1e-5
+
+
+def conv3x3(cin, cout, stride=1):
+    return nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        r = x if self.downsample is None else self.downsample(x)
+        y = Fnn.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return Fnn.relu(y + r)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = conv3x3(planes, planes, stride)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        r = x if self.downsample is None else self.downsample(x)
+        y = Fnn.relu(self.bn1(self.conv1(x)))
+        y = Fnn.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return Fnn.relu(y + r)
+
+
+class HighResolutionModule(nn.Module):
+    def __init__(self, channels, num_blocks=4, multi_scale_output=True):
+        super().__init__()
+        nb = len(channels)
+        self.branches = nn.ModuleList(
+            [nn.Sequential(*[BasicBlock(c, c) for _ in range(num_blocks)]) for c in channels])
+        fuse = []
+        for i in range(nb if multi_scale_output else 1):
+            row = []
+            for j in range(nb):
+                if j > i:
+                    row.append(nn.Sequential(nn.Conv2d(channels[j], channels[i], 1, bias=False),
+                                             nn.BatchNorm2d(channels[i]),
+                                             nn.Upsample(scale_factor=2 ** (j - i), mode='nearest')))
+                elif j == i:
+                    row.append(None)
+                else:
+                    steps = []
+                    for k in range(i - j):
+                        if k == i - j - 1:
+                            steps.append(nn.Sequential(conv3x3(channels[j], channels[i], 2), nn.BatchNorm2d(channels[i])))
+                        else:
+                            steps.append(nn.Sequential(conv3x3(channels[j], channels[j], 2), nn.BatchNorm2d(channels[j]),
+                                                       nn.ReLU(inplace=False)))
+                    row.append(nn.Sequential(*steps))
+            fuse.append(nn.ModuleList(row))
+        self.fuse_layers = nn.ModuleList(fuse)
+
+    def forward(self, xs):
+        xs = [b(x) for b, x in zip(self.branches, xs)]
+        out = []
+        for i, row in enumerate(self.fuse_layers):
+            y = None
+            for j, f in enumerate(row):
+                t = xs[j] if f is None else f(xs[j])
+                y = t if y is None else y + t
+            out.append(Fnn.relu(y))
+        return out
+
+
+class PoseHighResolutionNet(nn.Module):
+    """HRNet-W{c}: stem -> layer1 -> 3 multi-resolution stages -> 1x1 head (Appendix D of SURVEY.md)."""
+
+    def __init__(self, c=48, num_joints=17):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.conv2 = nn.Conv2d(64, 64, 3, 2, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(64)
+        down = nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256))
+        self.layer1 = nn.Sequential(Bottleneck(64, 64, downsample=down), Bottleneck(256, 64), Bottleneck(256, 64),
+                                    Bottleneck(256, 64))
+        ch = [c, 2 * c, 4 * c, 8 * c]
+        self.transition1 = nn.ModuleList([
+            nn.Sequential(conv3x3(256, ch[0]), nn.BatchNorm2d(ch[0]), nn.ReLU(inplace=False)),
+            nn.Sequential(nn.Sequential(conv3x3(256, ch[1], 2), nn.BatchNorm2d(ch[1]), nn.ReLU(inplace=False)))])
+        self.stage2 = nn.Sequential(HighResolutionModule(ch[:2]))
+        self.transition2 = nn.ModuleList([None, None, nn.Sequential(
+            nn.Sequential(conv3x3(ch[1], ch[2], 2), nn.BatchNorm2d(ch[2]), nn.ReLU(inplace=False)))])
+        self.stage3 = nn.Sequential(*[HighResolutionModule(ch[:3]) for _ in range(4)])
+        self.transition3 = nn.ModuleList([None, None, None, nn.Sequential(
+            nn.Sequential(conv3x3(ch[2], ch[3], 2), nn.BatchNorm2d(ch[3]), nn.ReLU(inplace=False)))])
+        self.stage4 = nn.Sequential(HighResolutionModule(ch), HighResolutionModule(ch),
+                                    HighResolutionModule(ch, multi_scale_output=False))
+        self.final_layer = nn.Conv2d(ch[0], num_joints, 1)
+
+    def features(self, x):
+        x = Fnn.relu(self.bn1(self.conv1(x)))
+        x = Fnn.relu(self.bn2(self.conv2(x)))
+        x = self.layer1(x)
+        xs = [self.transition1[0](x), self.transition1[1](x)]
+        xs = self.stage2[0](xs)
+        xs = xs + [self.transition2[2](xs[-1])]
+        for m in self.stage3:
+            xs = m(xs)
+        xs = xs + [self.transition3[3](xs[-1])]
+        for m in self.stage4:
+            xs = m(xs)
+        return xs[0]
+
+    def forward(self, x):
+        return self.final_layer(self.features(x))
+
+
+def init_random(model, seed=0):
+    """Seeded He-normal convs, BN gamma=1 beta=0 mean=0 var=1 (real weights are unavailable offline)."""
+    g = torch.Generator().manual_seed(seed)
+    for m in model.modules():
+        if isinstance(m, nn.Conv2d):
+            fan_out = m.out_channels * m.kernel_size[0] * m.kernel_size[1]
+            with torch.no_grad():
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_out) ** 0.5)
+                if m.bias is not None:
+                    m.bias.zero_()
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.ones_(m.weight); nn.init.zeros_(m.bias)
+            m.running_mean.zero_(); m.running_var.fill_(1.0)
+    for m in model.modules():          # damp the residual branches so activations stay O(1) through ~80 blocks
+        if isinstance(m, BasicBlock):
+            nn.init.constant_(m.bn2.weight, 0.3)
+        elif isinstance(m, Bottleneck):
+            nn.init.constant_(m.bn3.weight, 0.3)
+    return model
+
+
+def count_flops(c=48, num_joints=17, h=384, w=288):
+    """2*MAC of every conv for one crop, counted from the module table by a shape-only forward on the meta device."""
+    model = PoseHighResolutionNet(c, num_joints).to('meta')
+    total = [0]
+
+    def hook(m, inp, out):
+        total[0] += 2 * out.shape[1] * out.shape[2] * out.shape[3] * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+    hs = [m.register_forward_hook(hook) for m in model.modules() if isinstance(m, nn.Conv2d)]
+    with torch.no_grad():
+        model(torch.empty(1, 3, h, w, device='meta'))
+    for x in hs:
+        x.remove()
+    return total[0]
+
+
+def fold_batchnorm(model):
+    """Inference form: every (conv, BN) pair becomes one conv with bias (scale = gamma / sqrt(var + eps))."""
+    def fold(conv, bn):
+        s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        new = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, bias=True)
+        with torch.no_grad():
+            new.weight.copy_(conv.weight * s.reshape(-1, 1, 1, 1))
+            new.bias.copy_(bn.bias - bn.running_mean * s + (conv.bias * s if conv.bias is not None else 0))
+        return new
+
+    def walk(mod):
+        names = list(mod._modules.keys())
+        for a, b in zip(names, names[1:]):
+            ma, mb = mod._modules[a], mod._modules[b]
+            if isinstance(ma, nn.Conv2d) and isinstance(mb, nn.BatchNorm2d):
+                mod._modules[a] = fold(ma, mb)
+                mod._modules[b] = nn.Identity()
+        for m in mod._modules.values():
+            if m is not None:
+                walk(m)
+    model = model.eval()
+    walk(model)
+    return model
+
+
+class HRNetPose(object):
+    """Mirror of ``backend.HRPose.SimpleHRNet.HRNetPose``: ctor (c, nof_joints, checkpoint, model_name, resolution, ...),
+    ``predict(person_bbox_list, batch_size, conf_threshold) -> dump_results`` (ivclabpose.py:131-132,210)."""
+
+    def __init__(self, c, nof_joints, checkpoint_path, model_name='HRNet', resolution=(384, 288), hrpose_args=None,
+                 device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16):
+        assert model_name == 'HRNet' and int(nof_joints) == 17
+        if not torch.cuda.is_available():
+            raise RuntimeError('HRNetPose needs a GPU (the preprocessing / decode kernels are HIP only; no CPU fallback)')
+        self.lib = _lib.load()
+        self.device = torch.device('cuda:%d' % device)
+        self.resolution = tuple(resolution)
+        self.dtype = dtype
+        self.max_dets = max_dets
+        model = PoseHighResolutionNet(c, nof_joints)
+        if checkpoint_path and os.path.exists(checkpoint_path):
+            sd = torch.load(checkpoint_path, map_location='cpu')
+            model.load_state_dict(sd.get('model', sd) if isinstance(sd, dict) else sd)
+            self.weights = checkpoint_path
+        else:
+            init_random(model, seed)
+            self.weights = 'random(seed=%d)' % seed
+        model = fold_batchnorm(model)
+        self.head = model.final_layer.to(self.device).float()           # 1x1 head + decode stay float32
+        model.final_layer = nn.Identity()
+        self.model = model.to(self.device).to(dtype).to(memory_format=torch.channels_last).eval()
+        self.use_graph = use_graph
+        self._graphs = {}
+        self._pool = None
+        self.stream = torch.cuda.current_stream(self.device)
+
+    # -- conv stack (PyTorch-ROCm; hipGraph replay per batch size) -------------------------------------------------
+    def _forward(self, x):
+        f = self.model.features(x)
+        return self.head(f.float())
+
+    def heatmaps(self, x):
+        """x: (N,3,H,W) channels-last bf16 on the device -> (N,17,H/4,W/4) float32 (channels-last memory)."""
+        n = x.shape[0]
+        if not self.use_graph:
+            with torch.no_grad():
+                return self._forward(x)
+        g = self._graphs.get(n)
+        if g is None:
+            static_in = torch.empty_like(x)
+            static_in.copy_(x)
+            with torch.no_grad():
+                s = torch.cuda.Stream(self.device)
+                s.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(s):
+                    for _ in range(2):
+                        self._forward(static_in)
+                torch.cuda.current_stream(self.device).wait_stream(s)
+                graph = torch.cuda.CUDAGraph()
+                if self._pool is None:
+                    self._pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(graph, pool=self._pool):
+                    static_out = self._forward(static_in)
+            g = (graph, static_in, static_out)
+            self._graphs[n] = g
+        graph, static_in, static_out = g
+        if static_in.data_ptr() != x.data_ptr():
+            static_in.copy_(x)
+        graph.replay()
+        return static_out
+
+    def input_buffer(self, n):
+        """The (N,3,H,W) channels-last bf16 tensor the preprocessing kernel writes; the graph's own input when one
+        exists, so no copy is needed."""
+        g = self._graphs.get(n)
+        if g is not None:
+            return g[1]
+        H, W = self.resolution
+        return torch.empty((n, 3, H, W), dtype=self.dtype, device=self.device).contiguous(memory_format=torch.channels_last)
+
+    # -- HIP kernels around it -----------------------------------------------------------------------------------------
+    def preprocess(self, frame_ptrs, frame_h, frame_w, view_of, boxes, out):
+        """frame_ptrs: int64 device tensor of per-view frame addresses; view_of int32 (N), boxes float32 (N,4) xywh."""
+        H, W = self.resolution
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.pam_preprocess_crops(C.c_void_p(st), int(view_of.numel()), C.c_void_p(frame_ptrs.data_ptr()),
+                                           int(frame_h), int(frame_w), C.c_void_p(view_of.data_ptr()),
+                                           C.c_void_p(boxes.data_ptr()), H, W, C.c_void_p(out.data_ptr()))
+        if rc != 0:
+            raise _lib.PamError('pam_preprocess_crops failed: %d' % rc)
+
+    def decode(self, hm, view_of, slot_of, boxes, det, kp=None):
+        """hm (N,17,h,w) float32 (channels-last or contiguous) -> det (C,max_dets,17,3) float64 rows (y,x,score)."""
+        n, j, h, w = hm.shape
+        nchw = hm.is_contiguous()
+        assert nchw or hm.is_contiguous(memory_format=torch.channels_last)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.pam_decode_heatmaps(C.c_void_p(st), n, C.c_void_p(hm.data_ptr()), 1 if nchw else 0, h, w,
+                                          C.c_void_p(view_of.data_ptr()), C.c_void_p(slot_of.data_ptr()),
+                                          C.c_void_p(boxes.data_ptr()), det.shape[1], C.c_void_p(det.data_ptr()),
+                                          C.c_void_p(kp.data_ptr()) if kp is not None else None)
+        if rc != 0:
+            raise _lib.PamError('pam_decode_heatmaps failed: %d' % rc)
+
+    # -- the reference-shaped entry point ------------------------------------------------------------------------------
+    def predict(self, person_bbox_list, batch_size=20, conf_threshold=0.4):
+        """person_bbox_list[view] = list of dicts with 'bbox' [x, y, w, h] and 'data' (BGR uint8 HxWx3 ndarray or CUDA
+        tensor) -> dump_results[view] = list of dicts {bbox, keypoints (51: x, y, score), keypoints_score (17), feature}."""
+        views, boxes, frames = [], [], {}
+        for v, persons in enumerate(person_bbox_list):
+            for p in persons:
+                views.append(v); boxes.append(p['bbox'])
+                if v not in frames:
+                    d = p['data']
+                    if not torch.is_tensor(d):
+                        d = torch.from_numpy(np.ascontiguousarray(d))
+                    frames[v] = d.to(self.device, non_blocking=True).contiguous()
+        n = len(views)
+        out = [[] for _ in person_bbox_list]
+        if n == 0:
+            return out
+        any_frame = next(iter(frames.values()))
+        fh, fw = any_frame.shape[0], any_frame.shape[1]
+        ptrs = torch.tensor([frames[v].data_ptr() if v in frames else 0 for v in range(len(person_bbox_list))],
+                            dtype=torch.int64, device=self.device)
+        view_of = torch.tensor(views, dtype=torch.int32, device=self.device)
+        slot_of = torch.tensor([sum(1 for q in views[:i] if q == views[i]) for i in range(n)], dtype=torch.int32,
+                               device=self.device)
+        bx = torch.tensor(boxes, dtype=torch.float32, device=self.device).reshape(n, 4)
+        det = torch.zeros((len(person_bbox_list), max(self.max_dets, int(slot_of.max().item()) + 1), 17, 3),
+                          dtype=torch.float64, device=self.device)
+        kp = torch.empty((n, 17, 3), dtype=torch.float32, device=self.device)
+        for s in range(0, n, batch_size):
+            e = min(n, s + batch_size)
+            x = self.input_buffer(e - s)
+            self.preprocess(ptrs, fh, fw, view_of[s:e], bx[s:e], x)
+            hm = self.heatmaps(x)
+            self.decode(hm, view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
+        kp_h = kp.cpu().numpy()
+        for i in range(n):
+            k = kp_h[i].astype(np.float64)
+            out[views[i]].append(dict(bbox=list(boxes[i]), keypoints=k.reshape(-1).tolist(),
+                                      keypoints_score=k[:, 2].tolist(), feature=[]))
+        return out
+
+
+def smoke_check():
+    """Tiny self-check used by __graft_entry__.smoke(): 2 crops, decode vs torch arg-max, preprocess vs torch."""
+    dev = torch.device('cuda:0')
+    net = HRNetPose(48, 17, None, resolution=(384, 288), use_graph=False)
+    g = torch.Generator().manual_seed(0)
+    frame = torch.randint(0, 256, (2, 480, 640, 3), dtype=torch.uint8, generator=g).to(dev)
+    ptrs = torch.tensor([frame[0].data_ptr(), frame[1].data_ptr()], dtype=torch.int64, device=dev)
+    view_of = torch.tensor([0, 1], dtype=torch.int32, device=dev)
+    slot_of = torch.tensor([0, 0], dtype=torch.int32, device=dev)
+    boxes = torch.tensor([[100.0, 50.0, 200.0, 300.0], [300.5, 100.25, 150.0, 280.0]], dtype=torch.float32, device=dev)
+    x = net.input_buffer(2)
+    net.preprocess(ptrs, 480, 640, view_of, boxes, x)
+    ref = reference_preprocess(frame, view_of, boxes, (384, 288))
+    err = (x.float() - ref).abs().max().item()
+    assert err < 0.03, err                               # bf16 rounding of values in [-2.2, 2.7]
+    hm = net.heatmaps(x)
+    det = torch.zeros((2, 4, 17, 3), dtype=torch.float64, device=dev)
+    net.decode(hm, view_of, slot_of, boxes, det)
+    exp = reference_decode(hm, boxes)
+    assert torch.equal(det[:, 0], exp), (det[:, 0] - exp).abs().max()
+
+
+def reference_preprocess(frames, view_of, boxes, resolution):
+    """Plain torch float32 restatement of the preprocessing kernel (tests): half-pixel bilinear sample of the box."""
+    H, W = resolution
+    n = view_of.numel()
+    out = torch.empty((n, 3, H, W), dtype=torch.float32, device=frames.device)
+    fh, fw = frames.shape[1], frames.shape[2]
+    mean = torch.tensor([0.485, 0.456, 0.406], device=frames.device).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=frames.device).view(3, 1, 1)
+    for i in range(n):
+        img = frames[int(view_of[i])].float()
+        bx, by, bw, bh = [boxes[i, k] for k in range(4)]
+        sx = (bx + (torch.arange(W, device=frames.device, dtype=torch.float32) + 0.5) * (bw / W) - 0.5).clamp(0, fw - 1)
+        sy = (by + (torch.arange(H, device=frames.device, dtype=torch.float32) + 0.5) * (bh / H) - 0.5).clamp(0, fh - 1)
+        x0 = sx.floor().long(); y0 = sy.floor().long()
+        x1 = (x0 + 1).clamp(max=fw - 1); y1 = (y0 + 1).clamp(max=fh - 1)
+        fx = (sx - x0.float()).view(1, W, 1); fy = (sy - y0.float()).view(H, 1, 1)
+        a = img[y0][:, x0]; b = img[y0][:, x1]; c = img[y1][:, x0]; d = img[y1][:, x1]
+        top = a + (b - a) * fx; bot = c + (d - c) * fx
+        v = (top + (bot - top) * fy) / 255.0                    # (H,W,3) BGR
+        out[i] = (v.flip(2).permute(2, 0, 1) - mean) / std
+    return out
+
+
+def reference_decode(hm, boxes):
+    """torch restatement of the decode kernel: hard arg-max (first maximum), upstream SimpleHRNet box mapping."""
+    n, j, h, w = hm.shape
+    flat = hm.float().reshape(n, j, h * w)
+    val, idx = flat.max(dim=2)
+    # torch.max may return any maximal index on ties; recompute the first one
+    first = (flat == val.unsqueeze(2)).float().argmax(dim=2)
+    py = (first // w).double(); px = (first % w).double()
+    b = boxes.double()
+    y = (py / h * b[:, 3:4] + b[:, 1:2]).float().double()
+    x = (px / w * b[:, 2:3] + b[:, 0:1]).float().double()
+    return torch.stack([y, x, val.double()], dim=2)

@@ -1,0 +1,69 @@
+"""On-device per-frame pipeline: crop/resize/normalise (HIP) -> HRNet-W48 conv stack (PyTorch-ROCm, hipGraph) ->
+heat-map decode (HIP) -> [all-gather of per-view keypoints when views are sharded] -> fused tracker frame kernel (HIP).
+Nothing returns to the host inside a frame; the output record is copied out asynchronously.
+
+This is the device-resident form of testmodel.py's loop body (/root/reference/src/testmodel.py:59-69):
+PersonPoseDetect + PersonTrack_Project3DPose."""
+import numpy as np
+import torch
+
+from . import _lib
+from .distributed import ViewGather, view_partition
+from .hrnet import HRNetPose
+
+NUM_JOINTS = 17
+
+
+class FramePipeline(object):
+    def __init__(self, calib_cameras, matcher, conf_threshold, frame_hw, max_dets=8, max_tracks=16, device=0, world=1,
+                 rank=0, group=None, use_graph=True, hrnet=True, seed=0):
+        self.device = torch.device('cuda:%d' % device)
+        torch.cuda.set_device(self.device)
+        self.cams = calib_cameras
+        self.C = len(calib_cameras)
+        self.max_dets = max_dets
+        self.frame_h, self.frame_w = frame_hw
+        self.world, self.rank = world, rank
+        self.params = _lib.make_params(matcher, conf_threshold)
+        self.handle = _lib.Handle(self.C, self.params, max_dets=max_dets, max_tracks=max_tracks, n_scenes=1, device=device)
+        self.handle.set_cameras(np.stack([c.P for c in calib_cameras]), np.stack([c.F for c in calib_cameras]),
+                                np.stack([c.RK_INV for c in calib_cameras]), np.stack([c.position for c in calib_cameras]))
+        self.net = HRNetPose(48, 17, None, resolution=(384, 288), device=device, use_graph=use_graph, seed=seed,
+                             max_dets=max_dets) if hrnet else None
+        self.gather = ViewGather(self.C, max_dets, world, rank, self.device, group)
+        self.mine = self.gather.mine
+        # decode target: this rank's views only, (len(mine), max_dets, 17, 3)
+        self.det_local = torch.zeros((max(1, len(self.mine)), max_dets, NUM_JOINTS, 3), dtype=torch.float64, device=self.device)
+        L = self.handle.layout
+        self.out_i = torch.zeros((1, L.int_words), dtype=torch.int32).pin_memory()
+        self.out_d = torch.zeros((1, L.dbl_words), dtype=torch.float64).pin_memory()
+        self.ev = None
+
+    def stream_ptr(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def pose_step(self, frame_ptrs, view_local, slot_of, boxes, time_events=None):
+        """HRNet side for this rank's crops.  view_local: int32 (N,) index into self.mine; writes self.det_local."""
+        n = int(view_local.numel())
+        if n == 0 or self.net is None:
+            return
+        x = self.net.input_buffer(n)
+        self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, view_local, boxes, x)
+        if time_events is not None:
+            time_events[0].record()
+        hm = self.net.heatmaps(x)
+        if time_events is not None:
+            time_events[1].record()
+        self.net.decode(hm, view_local, slot_of, boxes, self.det_local)
+
+    def track_step(self, frame_id, n_det_local, det_local, fetch=True):
+        """Exchange (if sharded) + fused tracker kernel on the gathered keypoints; async fetch of the record."""
+        n_det, det = self.gather.gather(n_det_local, det_local)
+        st = self.stream_ptr()
+        self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
+        if fetch:
+            self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
+
+    def results(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        return self.handle.decode(0, self.out_i.numpy(), self.out_d.numpy())

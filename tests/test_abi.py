@@ -1,0 +1,81 @@
+"""CPU-side checks: the C-ABI library builds/loads here (no GPU) and exports every symbol include/pam.h declares; host
+logic that needs no device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pam
+from pam import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'pam.h')).read()
+    return sorted(set(re.findall(r'\b(pam_[a-z_0-9]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libpam_hip.so')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_params_struct_matches_header():
+    assert ctypes.sizeof(_lib.PamParams) == 7 * 8 + 6 * 4 + (16 + 16 + 64 + 4) * 8
+    p = _lib.make_params(synth.MATCHER_CFG['Shelf'], 0.5)
+    assert p.n_taps_body == 2 and p.n_taps_arm == 4              # radius int(4*0.3+.5)=1, int(4*0.8+.5)=3
+    assert abs(sum([p.taps_body[0]] + [2 * p.taps_body[i] for i in range(1, 2)]) - 1) < 1e-15
+    assert p.w_lambda_t[0] == 1.0 and abs(p.w_lambda_t[3] - np.exp(-15.0)) < 1e-20
+    assert p.count_gate == 10 and p.max_age == 10 and p.n_init == 3
+
+
+def test_gaussian_taps_match_scipy():
+    from scipy.ndimage import gaussian_filter1d
+    for sigma in (0.3, 0.6, 0.8, 1.7):
+        w = _lib.gaussian_taps(sigma)
+        r = len(w) - 1
+        imp = np.zeros(2 * r + 1); imp[r] = 1.0
+        k = gaussian_filter1d(imp, sigma=sigma, mode='constant')
+        np.testing.assert_allclose(k[r:], w, rtol=0, atol=1e-16)
+
+
+def test_unpack_dump_layout():
+    """a2: (x, y, .) dump rows become (y, x, score) float64 (ivclabpose.py:236-244)."""
+    from pam.ivclabpose import ivclabpose
+    seq = synth.make_sequence('S1', n_frames=2, seed=0)
+    pbl, dr = synth.to_dump_results(seq['frames'][1])
+    poses = ivclabpose._unpack(dr)
+    for v, d in enumerate(seq['frames'][1]):
+        assert poses[v].dtype == np.float64 and poses[v].shape == (len(d), 17, 3)
+        assert np.array_equal(poses[v][:, :, 0], d[:, :, 1]) and np.array_equal(poses[v][:, :, 1], d[:, :, 0])
+        assert np.array_equal(poses[v][:, :, 2], d[:, :, 2])
+    assert ivclabpose._unpack([[], []])[0].shape == (0, 17, 3)
+
+
+def test_hrnet_definition():
+    from pam import hrnet
+    assert abs(hrnet.count_flops() / 1e9 - 70.6) < 0.1            # 35.3 GMAC per 384x288 crop
+    m = hrnet.PoseHighResolutionNet()
+    keys = m.state_dict().keys()
+    for k in ('conv1.weight', 'layer1.0.downsample.0.weight', 'transition1.1.0.0.weight', 'stage2.0.branches.1.3.conv2.weight',
+              'stage3.3.fuse_layers.2.0.1.0.weight', 'transition3.3.0.0.weight', 'stage4.2.fuse_layers.0.3.0.weight',
+              'final_layer.bias'):
+        assert k in keys, k
+    assert not any(k.startswith('stage4.2.fuse_layers.1') for k in keys)

@@ -1,0 +1,55 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the view partition + the single all-gather per frame."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import pam
+from pam.distributed import ViewGather, view_partition
+
+
+def test_view_partition():
+    assert view_partition(5, 1) == [[0, 1, 2, 3, 4]]
+    assert view_partition(5, 2) == [[0, 1, 2], [3, 4]]
+    assert [len(p) for p in view_partition(31, 8)] == [4, 4, 4, 4, 4, 4, 4, 3]
+    p = view_partition(5, 8)
+    assert sorted(v for q in p for v in q) == list(range(5)) and sum(1 for q in p if not q) == 3
+    for C in (3, 5, 31):
+        for W in (1, 2, 4, 8):
+            q = view_partition(C, W)
+            assert sorted(v for r in q for v in r) == list(range(C))
+            assert all(r == sorted(r) for r in q)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, C, max_dets, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = np.random.default_rng(0)                       # same stream on all ranks = the "global" truth
+    n_det = rng.integers(0, max_dets + 1, size=(3, C)).astype(np.int32)
+    det = rng.normal(size=(3, C, max_dets, 17, 3))
+    g = ViewGather(C, max_dets, world, rank, torch.device('cpu'))
+    ok = True
+    for t in range(3):
+        mine = g.mine
+        nd, dd = g.gather(torch.tensor(n_det[t, mine], dtype=torch.int32), torch.tensor(det[t][mine]).reshape(len(mine), max_dets, 17, 3))
+        ok &= bool(np.array_equal(nd.numpy(), n_det[t])) and bool(np.array_equal(dd.numpy(), det[t]))
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_gather_world2_gloo():
+    for C in (5, 3):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        port = _free_port()
+        mp.spawn(_worker, args=(2, port, C, 4, ret), nprocs=2, join=True)
+        assert ret[0] and ret[1]

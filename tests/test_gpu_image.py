@@ -1,0 +1,156 @@
+"""GPU: the image-side HIP kernels (crop/resize/normalise, heat-map decode) against plain torch float32 restatements,
+the bf16 conv stack against its own fp32 form, and the on-device pipeline decode -> tracker against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import pam
+from pam import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def net():
+    from pam import hrnet
+    return hrnet.HRNetPose(48, 17, None, resolution=(384, 288), use_graph=False)
+
+
+def test_preprocess_vs_torch(net):
+    from pam import hrnet
+    dev = net.device
+    g = torch.Generator().manual_seed(0)
+    frames = torch.randint(0, 256, (3, 288, 360, 3), dtype=torch.uint8, generator=g).to(dev)
+    ptrs = torch.tensor([frames[i].data_ptr() for i in range(3)], dtype=torch.int64, device=dev)
+    view_of = torch.tensor([0, 2, 1, 2], dtype=torch.int32, device=dev)
+    boxes = torch.tensor([[10, 20, 100, 200], [-15.5, -8.25, 120, 260], [300, 200, 90, 120], [0, 0, 360, 288]],
+                         dtype=torch.float32, device=dev)          # includes boxes leaving the frame (border replicate)
+    x = net.input_buffer(4)
+    assert x.is_contiguous(memory_format=torch.channels_last) and x.dtype == torch.bfloat16
+    net.preprocess(ptrs, 288, 360, view_of, boxes, x)
+    ref = hrnet.reference_preprocess(frames, view_of, boxes, (384, 288))
+    torch.cuda.synchronize()
+    assert (x.float() - ref).abs().max().item() <= 2.0 ** -7 * 2.7 + 1e-3       # one bf16 ulp at |v| <= 2.7
+    assert torch.equal(x, ref.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)) or \
+        (x.float() - ref.to(torch.bfloat16).float()).abs().max().item() <= 2.0 ** -6
+
+
+@pytest.mark.parametrize('layout', ['nhwc', 'nchw'])
+def test_decode_vs_torch(net, layout):
+    from pam import hrnet
+    dev = net.device
+    g = torch.Generator().manual_seed(1)
+    n = 5
+    hm = torch.randn((n, 17, 96, 72), generator=g).to(dev)
+    hm[0, 3] = 0.25                                   # all-equal map: first index must win
+    hm[1, 5, 10, 11] = 9.0; hm[1, 5, 40, 2] = 9.0     # exact tie: smaller flat index wins
+    hm[2, 0, 95, 71] = 50.0                           # last cell
+    if layout == 'nhwc':
+        hm = hm.contiguous(memory_format=torch.channels_last)
+    view_of = torch.tensor([0, 0, 1, 2, 2], dtype=torch.int32, device=dev)
+    slot_of = torch.tensor([0, 1, 0, 0, 1], dtype=torch.int32, device=dev)
+    boxes = (torch.rand((n, 4), generator=g) * 300 + 20).to(dev)
+    det = torch.zeros((3, 4, 17, 3), dtype=torch.float64, device=dev)
+    kp = torch.zeros((n, 17, 3), dtype=torch.float32, device=dev)
+    net.decode(hm, view_of, slot_of, boxes, det, kp)
+    exp = hrnet.reference_decode(hm, boxes)
+    torch.cuda.synchronize()
+    for i in range(n):
+        got = det[int(view_of[i]), int(slot_of[i])]
+        assert torch.equal(got, exp[i]), (i, (got - exp[i]).abs().max())
+        assert torch.equal(kp[i][:, 0].double(), exp[i][:, 1]) and torch.equal(kp[i][:, 1].double(), exp[i][:, 0])
+    assert float(det[0, 0, 3, 0]) == float(boxes[0, 1]) and float(det[0, 0, 3, 2]) == 0.25
+    assert float(det[0, 1, 5, 0]) == float(np.float32(10 / 96 * float(boxes[1, 3]) + float(boxes[1, 1])))
+
+
+def test_bf16_stack_vs_fp32(net):
+    """Self-consistency of the conv stack (parity with the authors' backend is unpinned): bf16 channels-last folded-BN
+    heat-maps vs the same weights in fp32 eager; reports arg-max drift."""
+    from pam import hrnet
+    dev = net.device
+    ref = hrnet.fold_batchnorm(hrnet.init_random(hrnet.PoseHighResolutionNet(), seed=0)).to(dev).eval()
+    g = torch.Generator().manual_seed(2)
+    x32 = torch.randn((2, 3, 384, 288), generator=g).to(dev)
+    with torch.no_grad():
+        h32 = ref(x32)
+        hb = net.heatmaps(x32.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    rel = ((hb.float() - h32).norm() / h32.norm()).item()
+    assert rel < 0.05, rel
+
+
+def test_hipgraph_replay_matches_eager():
+    from pam import hrnet
+    a = hrnet.HRNetPose(48, 17, None, use_graph=False)
+    b = hrnet.HRNetPose(48, 17, None, use_graph=True)
+    x = a.input_buffer(3)
+    x.copy_(torch.randn(x.shape, device=x.device).to(x.dtype))
+    y0 = a.heatmaps(x).clone()
+    y1 = b.heatmaps(x).clone()
+    y2 = b.heatmaps(x).clone()                      # replay
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert (y0 - y1).abs().max().item() <= 1e-2 * y0.abs().max().item()
+
+
+def test_device_pipeline_decode_to_tracker_vs_oracle():
+    """Heat-maps with planted peaks -> k_decode -> det buffer (device) -> k_frame, no host round trip; the oracle is fed the
+    torch-decoded keypoints.  ids / view sets bit-exact, 3D <= 1e-6 m."""
+    from pam import hrnet
+    from pam.ivclabpose import Camera, fundamental_matrices
+    from pam.pipeline import FramePipeline
+    from oracle import cpu_ref as O
+    size = 'S2'
+    meta = synth.SIZES[size]
+    seq = synth.make_sequence(size, n_frames=30, seed=4, occlusion_every=7, empty_view_every=11, birth_death_frame=15)
+    cfg = dict(synth.MATCHER_CFG['Shelf']); conf = cfg.pop('CONF_THRESHOLD')
+    P32 = seq['calib']['P'].astype(np.float32); K32 = seq['calib']['K'].astype(np.float32); RT32 = seq['calib']['RT'].astype(np.float32)
+    Fm = fundamental_matrices(K32, RT32)
+    cams = [Camera(j, P32[j], K32[j], RT32[j], Fm[j]) for j in range(meta['C'])]
+    pipe = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=8, max_tracks=16, hrnet=False)
+    pipe.net = hrnet.HRNetPose(48, 17, None, use_graph=False, max_dets=8)
+    dev = pipe.device
+    ref = O.OracleIvclabpose(cfg, conf)
+    ref.GetCameraParameters(seq['calib'], F=Fm)
+    emitted = 0
+    for t, views in enumerate(seq['frames']):
+        vl, sl, bx, cells = [], [], [], []
+        for v, dets in enumerate(views):
+            for s, kp in enumerate(dets):
+                x0, y0, x1, y1 = kp[:, 0].min(), kp[:, 1].min(), kp[:, 0].max(), kp[:, 1].max()
+                b = [x0 - 0.125 * (x1 - x0), y0 - 0.125 * (y1 - y0), 1.25 * (x1 - x0), 1.25 * (y1 - y0)]
+                vl.append(v); sl.append(s); bx.append(b)
+                px = np.clip(np.round((kp[:, 0] - b[0]) / b[2] * 72), 0, 71).astype(int)
+                py = np.clip(np.round((kp[:, 1] - b[1]) / b[3] * 96), 0, 95).astype(int)
+                cells.append((py, px, kp[:, 2]))
+        n = len(vl)
+        hm = torch.zeros((n, 17, 96, 72), dtype=torch.float32)
+        for i, (py, px, sc) in enumerate(cells):
+            hm[i, torch.arange(17), torch.tensor(py), torch.tensor(px)] = torch.tensor(sc, dtype=torch.float32)
+        hm = hm.to(dev).contiguous(memory_format=torch.channels_last)
+        view_of = torch.tensor(vl, dtype=torch.int32, device=dev); slot_of = torch.tensor(sl, dtype=torch.int32, device=dev)
+        boxes = torch.tensor(bx, dtype=torch.float32, device=dev).reshape(n, 4)
+        pipe.det_local.zero_()
+        if n:
+            pipe.net.decode(hm, view_of, slot_of, boxes, pipe.det_local)
+        n_det = torch.tensor([len(d) for d in views], dtype=torch.int32, device=dev)
+        pipe.track_step(t, n_det, pipe.det_local)
+        got = pipe.results()
+        # oracle on the torch-decoded keypoints
+        dec = hrnet.reference_decode(hm, boxes).cpu().numpy() if n else np.zeros((0, 17, 3))
+        per_view = [[] for _ in views]
+        for i in range(n):
+            per_view[vl[i]].append(dec[i])
+        if n == 0:
+            continue
+        ref.tracker.step(t, [np.array(p).reshape(-1, 17, 3) for p in per_view])
+        _, _, _, p3, jv, ids = ref.tracker.collect(t)
+        em = [tr for tr in got['tracks'] if tr['emitted']]
+        assert [tr['track_id'] for tr in em] == list(ids), t
+        for tr, e3, ejv in zip(em, p3, jv):
+            np.testing.assert_allclose(tr['pose3d'], e3.T, rtol=0, atol=1e-6)
+            out = [[] for _ in range(tr['V'])]
+            for j in range(17):
+                out[int(tr['nviews'][j]) - 1].append(j)
+            assert out == ejv
+        emitted += len(em)
+    assert emitted > 20
