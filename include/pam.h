@@ -10,7 +10,7 @@
  * code, with text available from pam_last_error(); no exceptions or callbacks cross the ABI; a handle owns its
  * device memory, is bound to one GPU and is not thread-safe.  "host" pointers are ordinary host memory, "dev"
  * pointers are device memory (e.g. torch tensor .data_ptr()); `stream` is a hipStream_t passed as void* (NULL =
- * the handle's own stream).  Keypoints are rows (y, x, score) in float64 -- the tracker-internal layout the
+ * the legacy null stream, which is what torch's default stream is).  Keypoints are rows (y, x, score) in float64 -- the tracker-internal layout the
  * reference builds at ivclabpose.py:236-244.
  */
 #ifndef PAM_H

@@ -774,12 +774,12 @@ static int launch_frame(PamHandle* h, hipStream_t s, int frame_id, const int* d_
 extern "C" int pam_frame_dev(PamHandle* h, void* stream, int frame_id, const int32_t* dev_n_det, const double* dev_det) {
     if (!h) return PAM_E_ARG;
     ARGCHK(h, dev_n_det && dev_det, "null device buffer");
-    return launch_frame(h, stream ? (hipStream_t)stream : h->stream, frame_id, dev_n_det, dev_det);
+    return launch_frame(h, (hipStream_t)stream, frame_id, dev_n_det, dev_det);
 }
 
 extern "C" int pam_fetch(PamHandle* h, void* stream, int32_t* host_out_i, double* host_out_d) {
     if (!h) return PAM_E_ARG;
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s = (hipStream_t)stream;
     if (host_out_i) HIPCHK(h, hipMemcpyAsync(host_out_i, h->d_out_i, sizeof(int) * (size_t)h->d.S * h->ol.int_words, hipMemcpyDeviceToHost, s));
     if (host_out_d) HIPCHK(h, hipMemcpyAsync(host_out_d, h->d_out_d, sizeof(double) * (size_t)h->d.S * h->ol.dbl_words, hipMemcpyDeviceToHost, s));
     return PAM_OK;
@@ -787,7 +787,7 @@ extern "C" int pam_fetch(PamHandle* h, void* stream, int32_t* host_out_i, double
 
 extern "C" int pam_sync(PamHandle* h, void* stream) {
     if (!h) return PAM_E_ARG;
-    HIPCHK(h, hipStreamSynchronize(stream ? (hipStream_t)stream : h->stream));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
     return PAM_OK;
 }
 
@@ -801,8 +801,8 @@ extern "C" int pam_frame(PamHandle* h, int frame_id, const int32_t* n_det, const
     HIPCHK(h, hipMemcpyAsync(h->d_det, det, sizeof(double) * (size_t)d.S * d.C * d.MAXP * J3, hipMemcpyHostToDevice, h->stream));
     int rc = launch_frame(h, h->stream, frame_id, h->d_ndet, h->d_det);
     if (rc) return rc;
-    rc = pam_fetch(h, h->stream, out_i, out_d);
-    if (rc) return rc;
+    if (out_i) HIPCHK(h, hipMemcpyAsync(out_i, h->d_out_i, sizeof(int) * (size_t)d.S * h->ol.int_words, hipMemcpyDeviceToHost, h->stream));
+    if (out_d) HIPCHK(h, hipMemcpyAsync(out_d, h->d_out_d, sizeof(double) * (size_t)d.S * h->ol.dbl_words, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (out_i)
         for (int s = 0; s < d.S; ++s)
