@@ -148,10 +148,22 @@ int pam_op_hyp_cost(PamHandle* h, int n_members, const int32_t* cids, const doub
  * slot (view_of[i], slot_of[i]).  All pointers are device pointers; asynchronous on `stream`. */
 int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames /*dev array of n_views frame ptrs*/,
                          int frame_h, int frame_w, const int32_t* dev_view_of, const float* dev_boxes,
-                         int out_h, int out_w, void* dev_out_bf16);
+                         int out_h, int out_w, int out_c /*3, or 8 = RGB + 5 zero channels*/, void* dev_out_bf16);
 int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw, int hm_h, int hm_w,
                         const int32_t* dev_view_of, const int32_t* dev_slot_of, const float* dev_boxes,
                         int max_dets, double* dev_det, float* dev_kp_xyc /*optional n*17*3 (x,y,conf) or NULL*/);
+
+/* ---- HRNet conv stack (a1) as hand-written MFMA kernels -------------------------------------------------------
+ * pam_conv2d_nhwc_bf16: NHWC bf16 convolution (KH,KW in {1,3}; stride 1/2; Cin % 8 == 0; Cout % 48 == 0 or % 64 == 0) as an
+ * implicit GEMM on v_mfma_f32_16x16x32_bf16 with fused epilogue out = [relu](conv + bias [+ residual]).  w_packed is
+ * [Cout][Kpad] bf16, k = (ky, kx, cin) flattened, zero-padded to Kpad = roundup(KH*KW*Cin, 64); bias float32 or NULL;
+ * residual NHWC bf16 of the output shape or NULL.  tile_cfg < 0 = choose automatically.
+ * pam_upsample_add_nhwc_bf16: the HRNet fuse-layer sum out = [relu](base + sum_t nearest_upsample(term_t, 2^shift_t)). */
+int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const float* bias, const void* residual,
+                         void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                         int relu, int tile_cfg);
+int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, const void* const* terms,
+                               const int32_t* shifts, void* out, int N, int H, int W, int C, int relu);
 
 #ifdef __cplusplus
 }

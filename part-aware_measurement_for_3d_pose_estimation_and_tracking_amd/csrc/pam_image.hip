@@ -15,7 +15,7 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest
 // uint8 frame, BGR->RGB, /255, ImageNet mean/std, bf16 NHWC store (6 B per thread, contiguous across the wave).
 __global__ __launch_bounds__(256) void k_preprocess_crops(int n, const uint8_t* const* __restrict__ frames, int H, int W,
                                                           const int* __restrict__ view_of, const float* __restrict__ boxes,
-                                                          int oh, int ow, uint16_t* __restrict__ out) {
+                                                          int oh, int ow, int oc, uint16_t* __restrict__ out) {
     const int crop = blockIdx.y;
     const int px = blockIdx.x * blockDim.x + threadIdx.x;
     if (crop >= n || px >= oh * ow) return;
@@ -42,8 +42,14 @@ __global__ __launch_bounds__(256) void k_preprocess_crops(int n, const uint8_t* 
         const float v = (top + (bot - top) * fy) * (1.0f / 255.0f);
         o[c] = f32_to_bf16((v - mean[c]) * istd[c]);
     }
-    uint16_t* dst = out + (((size_t)crop * oh + oy) * ow + ox) * 3;
-    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    if (oc == 3) {
+        uint16_t* dst = out + (((size_t)crop * oh + oy) * ow + ox) * 3;
+        dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+    } else {            // 8-channel form for the MFMA conv kernel (Cin % 8 == 0): RGB + 5 zero channels, one 16-B store
+        uint4 v;
+        v.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); v.y = (uint32_t)o[2]; v.z = 0; v.w = 0;
+        *(uint4*)(out + (((size_t)crop * oh + oy) * ow + ox) * 8) = v;
+    }
 }
 
 struct Best { float v; int i; };
@@ -140,12 +146,12 @@ __global__ __launch_bounds__(256) void k_decode_nchw(int n, const float* __restr
 
 extern "C" int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames, int frame_h, int frame_w,
                                     const int32_t* dev_view_of, const float* dev_boxes, int out_h, int out_w,
-                                    void* dev_out_bf16) {
-    if (n < 0 || !dev_frames || !dev_view_of || !dev_boxes || !dev_out_bf16 || out_h <= 0 || out_w <= 0) return PAM_E_ARG;
+                                    int out_c, void* dev_out_bf16) {
+    if (n < 0 || !dev_frames || !dev_view_of || !dev_boxes || !dev_out_bf16 || out_h <= 0 || out_w <= 0 || (out_c != 3 && out_c != 8)) return PAM_E_ARG;
     if (n == 0) return PAM_OK;
     dim3 grid((out_h * out_w + 255) / 256, n);
     hipLaunchKernelGGL(k_preprocess_crops, grid, dim3(256), 0, (hipStream_t)stream, n, (const uint8_t* const*)dev_frames,
-                       frame_h, frame_w, dev_view_of, dev_boxes, out_h, out_w, (uint16_t*)dev_out_bf16);
+                       frame_h, frame_w, dev_view_of, dev_boxes, out_h, out_w, out_c, (uint16_t*)dev_out_bf16);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 

@@ -212,7 +212,7 @@ class HRNetPose(object):
     ``predict(person_bbox_list, batch_size, conf_threshold) -> dump_results`` (ivclabpose.py:131-132,210)."""
 
     def __init__(self, c, nof_joints, checkpoint_path, model_name='HRNet', resolution=(384, 288), hrpose_args=None,
-                 device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16):
+                 device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16, backend='hip'):
         assert model_name == 'HRNet' and int(nof_joints) == 17
         if not torch.cuda.is_available():
             raise RuntimeError('HRNetPose needs a GPU (the preprocessing / decode kernels are HIP only; no CPU fallback)')
@@ -232,7 +232,16 @@ class HRNetPose(object):
         model = fold_batchnorm(model)
         self.head = model.final_layer.to(self.device).float()           # 1x1 head + decode stay float32
         model.final_layer = nn.Identity()
-        self.model = model.to(self.device).to(dtype).to(memory_format=torch.channels_last).eval()
+        self.backend = backend
+        self.in_channels = 3
+        if backend == 'hip':                                            # hand-written MFMA conv kernels (csrc/pam_conv.hip)
+            from .hrnet_hip import HipHRNet
+            self.hip = HipHRNet(model, self.device)
+            self.in_channels = 8
+            self.model = None
+        else:                                                           # 'miopen': PyTorch-ROCm convs (reference for tests)
+            assert backend == 'miopen', backend
+            self.model = model.to(self.device).to(dtype).to(memory_format=torch.channels_last).eval()
         self.use_graph = use_graph
         self._graphs = {}
         self._pool = None
@@ -240,7 +249,7 @@ class HRNetPose(object):
 
     # -- conv stack (PyTorch-ROCm; hipGraph replay per batch size) -------------------------------------------------
     def _forward(self, x):
-        f = self.model.features(x)
+        f = self.hip.features(x) if self.backend == 'hip' else self.model.features(x)
         return self.head(f.float())
 
     def heatmaps(self, x):
@@ -280,7 +289,7 @@ class HRNetPose(object):
         if g is not None:
             return g[1]
         H, W = self.resolution
-        return torch.empty((n, 3, H, W), dtype=self.dtype, device=self.device).contiguous(memory_format=torch.channels_last)
+        return torch.empty((n, self.in_channels, H, W), dtype=self.dtype, device=self.device).contiguous(memory_format=torch.channels_last)
 
     # -- HIP kernels around it -----------------------------------------------------------------------------------------
     def preprocess(self, frame_ptrs, frame_h, frame_w, view_of, boxes, out):
@@ -289,7 +298,7 @@ class HRNetPose(object):
         st = torch.cuda.current_stream(self.device).cuda_stream
         rc = self.lib.pam_preprocess_crops(C.c_void_p(st), int(view_of.numel()), C.c_void_p(frame_ptrs.data_ptr()),
                                            int(frame_h), int(frame_w), C.c_void_p(view_of.data_ptr()),
-                                           C.c_void_p(boxes.data_ptr()), H, W, C.c_void_p(out.data_ptr()))
+                                           C.c_void_p(boxes.data_ptr()), H, W, int(out.shape[1]), C.c_void_p(out.data_ptr()))
         if rc != 0:
             raise _lib.PamError('pam_preprocess_crops failed: %d' % rc)
 
@@ -361,8 +370,9 @@ def smoke_check():
     x = net.input_buffer(2)
     net.preprocess(ptrs, 480, 640, view_of, boxes, x)
     ref = reference_preprocess(frame, view_of, boxes, (384, 288))
-    err = (x.float() - ref).abs().max().item()
+    err = (x[:, :3].float() - ref).abs().max().item()
     assert err < 0.03, err                               # bf16 rounding of values in [-2.2, 2.7]
+    assert x.shape[1] == 3 or float(x[:, 3:].float().abs().max()) == 0.0
     hm = net.heatmaps(x)
     det = torch.zeros((2, 4, 17, 3), dtype=torch.float64, device=dev)
     net.decode(hm, view_of, slot_of, boxes, det)

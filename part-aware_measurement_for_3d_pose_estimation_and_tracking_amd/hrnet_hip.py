@@ -1,0 +1,145 @@
+"""HRNet-W48 conv stack on the hand-written MFMA kernels of csrc/pam_conv.hip (no MIOpen in the loop).
+
+The folded (conv + bias) PyTorch module of hrnet.py is walked once into packed weights; ``forward`` then issues one
+``pam_conv2d_nhwc_bf16`` per convolution -- bias, residual add and ReLU fused into its epilogue -- plus one
+``pam_upsample_add_nhwc_bf16`` per fuse-layer output that has coarser inputs.  Activations are NHWC bf16 torch tensors
+(channels-last); torch is used for memory and the stream only.  The whole forward is hipGraph-capturable."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import hrnet as H
+
+
+class PackedConv(object):
+    def __init__(self, conv, device, pad_cin_to=None):
+        w = conv.weight.detach().float()
+        cout, cin, kh, kw = w.shape
+        if pad_cin_to is not None and cin < pad_cin_to:
+            w = torch.cat([w, torch.zeros(cout, pad_cin_to - cin, kh, kw)], dim=1)
+            cin = pad_cin_to
+        assert cin % 8 == 0 and (cout % 48 == 0 or cout % 64 == 0), (cin, cout)
+        ktot = kh * kw * cin
+        kpad = (ktot + 63) // 64 * 64
+        wp = torch.zeros((cout, kpad), dtype=torch.float32)
+        wp[:, :ktot] = w.permute(0, 2, 3, 1).reshape(cout, ktot)          # k = (ky, kx, cin), cin fastest
+        self.w = wp.to(torch.bfloat16).to(device).contiguous()
+        self.bias = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(cout)).to(device).contiguous()
+        self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+
+
+class HipHRNet(object):
+    def __init__(self, folded_model, device):
+        self.lib = _lib.load()
+        self.device = device
+        m = folded_model
+        P = lambda c, **kw: PackedConv(c, device, **kw)
+        self.conv1 = P(m.conv1, pad_cin_to=8)
+        self.conv2 = P(m.conv2)
+        self.layer1 = [dict(c1=P(b.conv1), c2=P(b.conv2), c3=P(b.conv3),
+                            down=P(b.downsample[0]) if b.downsample is not None else None) for b in m.layer1]
+        self.t1 = [P(m.transition1[0][0]), P(m.transition1[1][0][0])]
+        self.t2 = P(m.transition2[2][0][0])
+        self.t3 = P(m.transition3[3][0][0])
+        self.stage2 = [self._module(x) for x in m.stage2]
+        self.stage3 = [self._module(x) for x in m.stage3]
+        self.stage4 = [self._module(x) for x in m.stage4]
+        self.tile_cfg = -1
+
+    def _module(self, hm):
+        P = lambda c: PackedConv(c, self.device)
+        branches = [[(P(b.conv1), P(b.conv2)) for b in br] for br in hm.branches]
+        fuse = []
+        for i, row in enumerate(hm.fuse_layers):
+            r = []
+            for j, f in enumerate(row):
+                if f is None:
+                    r.append(None)
+                elif j > i:
+                    r.append(('up', P(f[0]), j - i))
+                else:
+                    r.append(('down', [P(step[0]) for step in f]))
+            fuse.append(r)
+        return dict(branches=branches, fuse=fuse)
+
+    # -- kernel launches -----------------------------------------------------------------------------------------------
+    def conv(self, op, x, res=None, relu=False):
+        n, cin, h, w = x.shape
+        assert cin == op.cin and x.is_contiguous(memory_format=torch.channels_last), (x.shape, op.cin)
+        ho = (h + 2 * op.pad - op.kh) // op.stride + 1
+        wo = (w + 2 * op.pad - op.kw) // op.stride + 1
+        y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device).contiguous(memory_format=torch.channels_last)
+        if op.cout == 1 or (ho == 1 and wo == 1):
+            y = y.as_strided(y.shape, (ho * wo * op.cout, 1, wo * op.cout, op.cout))
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        rc = self.lib.pam_conv2d_nhwc_bf16(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
+                                           C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
+                                           C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad,
+                                           1 if relu else 0, self.tile_cfg)
+        if rc != 0:
+            raise _lib.PamError('pam_conv2d_nhwc_bf16 failed (%d) for %s' % (rc, (x.shape, op.cout, op.kh, op.stride)))
+        return y
+
+    def upsample_add(self, base, terms, shifts, relu):
+        n, c, h, w = base.shape
+        y = torch.empty_like(base)
+        st = torch.cuda.current_stream(base.device).cuda_stream
+        ptrs = (C.c_void_p * 3)(*[C.c_void_p(t.data_ptr()) for t in terms] + [None] * (3 - len(terms)))
+        sh = (C.c_int32 * 3)(*(list(shifts) + [0] * (3 - len(shifts))))
+        rc = self.lib.pam_upsample_add_nhwc_bf16(C.c_void_p(st), C.c_void_p(base.data_ptr()), len(terms), ptrs, sh,
+                                                 C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0)
+        if rc != 0:
+            raise _lib.PamError('pam_upsample_add_nhwc_bf16 failed (%d)' % rc)
+        return y
+
+    # -- network ------------------------------------------------------------------------------------------------------
+    def _hr_module(self, mod, xs):
+        xs = list(xs)
+        for b, blocks in enumerate(mod['branches']):
+            x = xs[b]
+            for c1, c2 in blocks:
+                y = self.conv(c1, x, relu=True)
+                x = self.conv(c2, y, res=x, relu=True)
+            xs[b] = x
+        out = []
+        for i, row in enumerate(mod['fuse']):
+            ups = [(f[1], f[2], j) for j, f in enumerate(row) if f is not None and f[0] == 'up']
+            downs = [(f[1], j) for j, f in enumerate(row) if f is not None and f[0] == 'down']
+            acc = xs[i]
+            if ups:
+                terms = [self.conv(op, xs[j]) for op, _, j in ups]
+                acc = self.upsample_add(acc, terms, [s for _, s, _ in ups], relu=not downs)
+            for q, (chain, j) in enumerate(downs):
+                t = xs[j]
+                for k, op in enumerate(chain):
+                    if k < len(chain) - 1:
+                        t = self.conv(op, t, relu=True)
+                    else:
+                        acc = self.conv(op, t, res=acc, relu=(q == len(downs) - 1))
+            if not ups and not downs:
+                acc = torch.relu(acc)
+            out.append(acc)
+        return out
+
+    def features(self, x8):
+        """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
+        x = self.conv(self.conv1, x8, relu=True)
+        x = self.conv(self.conv2, x, relu=True)
+        for b in self.layer1:
+            r = x if b['down'] is None else self.conv(b['down'], x)
+            y = self.conv(b['c1'], x, relu=True)
+            y = self.conv(b['c2'], y, relu=True)
+            x = self.conv(b['c3'], y, res=r, relu=True)
+        xs = [self.conv(self.t1[0], x, relu=True), self.conv(self.t1[1], x, relu=True)]
+        for m in self.stage2:
+            xs = self._hr_module(m, xs)
+        xs = xs + [self.conv(self.t2, xs[-1], relu=True)]
+        for m in self.stage3:
+            xs = self._hr_module(m, xs)
+        xs = xs + [self.conv(self.t3, xs[-1], relu=True)]
+        for m in self.stage4:
+            xs = self._hr_module(m, xs)
+        return xs[0]

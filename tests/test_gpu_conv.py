@@ -1,0 +1,93 @@
+"""GPU: the hand-written MFMA convolution (csrc/pam_conv.hip) against a plain PyTorch fp32 reference of the same op on the
+same bf16-rounded inputs, over every (Cin, Cout, kernel, stride, tile) family HRNet-W48 uses, incl. ragged M / K tails."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import pam
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, residual, relu
+    (2, 24, 18, 48, 48, 3, 1, True, True),
+    (1, 96, 72, 48, 48, 3, 1, False, True),
+    (3, 12, 9, 96, 96, 3, 1, True, True),
+    (2, 12, 10, 192, 192, 3, 1, True, False),
+    (1, 12, 9, 384, 384, 3, 1, True, True),
+    (2, 24, 18, 64, 64, 3, 1, True, True),        # layer1 bottleneck 3x3 (64-wide N tiles)
+    (20, 96, 72, 48, 48, 3, 1, True, True),       # full-size branch-0 layer
+    (2, 13, 11, 8, 64, 3, 2, False, True),       # stem conv1 (3 -> 8 padded channels), odd sizes
+    (2, 20, 16, 64, 64, 3, 2, False, True),
+    (2, 16, 12, 64, 64, 1, 1, False, True),
+    (2, 16, 12, 64, 256, 1, 1, True, True),
+    (2, 16, 12, 256, 64, 1, 1, False, True),
+    (2, 16, 12, 256, 48, 3, 1, False, True),
+    (2, 16, 12, 256, 96, 3, 2, False, True),
+    (2, 12, 8, 384, 48, 1, 1, False, False),     # fuse 1x1
+    (2, 16, 12, 48, 96, 3, 2, True, False),      # fuse stride-2 with accumulate
+    (1, 7, 5, 96, 192, 3, 2, False, True),
+]
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from pam import hrnet, hrnet_hip
+    m = hrnet.PoseHighResolutionNet()
+    return hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet), hrnet_hip
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4])
+def test_conv_vs_torch(eng, case, tile):
+    from pam import _lib, hrnet_hip
+    n, h, w, cin, cout, k, stride, use_res, relu = case
+    if tile in (1, 3) and (cout // (48 if cout % 48 == 0 else 64)) % 2:
+        pytest.skip('tile needs an even number of N tiles')
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+    op = hrnet_hip.PackedConv(conv, dev)
+    x = torch.randn((n, cin, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn((n, cout, ho, wo), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last) if use_res else None
+    e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
+    e.lib = _lib.load(); e.device = dev; e.tile_cfg = tile
+    y = e.conv(op, x, res=res, relu=relu)
+    wq = conv.weight.detach().to(torch.bfloat16).float().to(dev)
+    ref = F.conv2d(x.float(), wq, conv.bias.detach().to(dev), stride, k // 2)
+    if use_res:
+        ref = ref + res.float()
+    if relu:
+        ref = torch.relu(ref)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    err = (y.float() - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 2e-2          # one bf16 rounding of the result + fp32 accumulation-order slack
+    assert bool((err <= tol).all()), (case, tile, err.max().item())
+
+
+def test_upsample_add_vs_torch():
+    from pam import _lib, hrnet_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
+    e.lib = _lib.load(); e.device = dev; e.tile_cfg = -1
+    base = torch.randn((2, 48, 24, 16), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    terms = [torch.randn((2, 48, 24 >> s, 16 >> s), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last) for s in (1, 2, 3)]
+    for nt in (1, 2, 3):
+        for relu in (False, True):
+            y = e.upsample_add(base, terms[:nt], [1, 2, 3][:nt], relu)
+            ref = base.float()
+            for s, t in zip((1, 2, 3), terms[:nt]):
+                ref = ref + F.interpolate(t.float(), scale_factor=2 ** s, mode='nearest')
+            if relu:
+                ref = torch.relu(ref)
+            torch.cuda.synchronize()
+            assert torch.equal(y, ref.to(torch.bfloat16))

@@ -30,9 +30,11 @@ def test_preprocess_vs_torch(net):
     net.preprocess(ptrs, 288, 360, view_of, boxes, x)
     ref = hrnet.reference_preprocess(frames, view_of, boxes, (384, 288))
     torch.cuda.synchronize()
-    assert (x.float() - ref).abs().max().item() <= 2.0 ** -7 * 2.7 + 1e-3       # one bf16 ulp at |v| <= 2.7
-    assert torch.equal(x, ref.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)) or \
-        (x.float() - ref.to(torch.bfloat16).float()).abs().max().item() <= 2.0 ** -6
+    assert x.shape[1] == 8 and float(x[:, 3:].float().abs().max()) == 0.0      # RGB + 5 zero channels for the MFMA conv
+    assert (x[:, :3].float() - ref).abs().max().item() <= 2.0 ** -7 * 2.7 + 1e-3       # one bf16 ulp at |v| <= 2.7
+    x3 = torch.empty((4, 3, 384, 288), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+    net.preprocess(ptrs, 288, 360, view_of, boxes, x3)                          # 3-channel form (MIOpen backend)
+    assert torch.equal(x3, x[:, :3])
 
 
 @pytest.mark.parametrize('layout', ['nhwc', 'nchw'])
@@ -71,11 +73,18 @@ def test_bf16_stack_vs_fp32(net):
     ref = hrnet.fold_batchnorm(hrnet.init_random(hrnet.PoseHighResolutionNet(), seed=0)).to(dev).eval()
     g = torch.Generator().manual_seed(2)
     x32 = torch.randn((2, 3, 384, 288), generator=g).to(dev)
+    x8 = torch.cat([x32, torch.zeros((2, 5, 384, 288), device=dev)], dim=1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        h32 = ref(x32)
-        hb = net.heatmaps(x32.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+        h32 = ref(x32.to(torch.bfloat16).float())
+        hb = net.heatmaps(x8)
+        mi = hrnet.HRNetPose(48, 17, None, use_graph=False, backend='miopen')
+        hm = mi.heatmaps(x32.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
     rel = ((hb.float() - h32).norm() / h32.norm()).item()
-    assert rel < 0.05, rel
+    rel_mi = ((hm.float() - h32).norm() / h32.norm()).item()
+    drift = (hb.float().flatten(2).argmax(2) != h32.flatten(2).argmax(2)).float().mean().item()
+    print('rel err vs fp32: hip %.4f miopen %.4f; arg-max drift %.3f' % (rel, rel_mi, drift))
+    assert rel < 0.03, rel
+    assert rel <= 1.5 * rel_mi + 5e-3
 
 
 def test_hipgraph_replay_matches_eager():
@@ -88,10 +97,7 @@ def test_hipgraph_replay_matches_eager():
     y1 = b.heatmaps(x).clone()
     y2 = b.heatmaps(x).clone()                      # replay
     torch.cuda.synchronize()
-    # MIOpen's split-K igemm kernels accumulate with atomics, so two runs are not bitwise equal; through ~80 bf16 layers
-    # that shows up as a few 1e-3 relative
-    assert ((y1 - y2).norm() / y1.norm()).item() < 2e-2
-    assert ((y0 - y1).norm() / y0.norm()).item() < 2e-2
+    assert torch.equal(y1, y2) and torch.equal(y0, y1)          # the MFMA conv kernels are deterministic
 
 
 def test_device_pipeline_decode_to_tracker_vs_oracle():

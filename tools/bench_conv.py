@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the MFMA conv kernel vs MIOpen (development tool)."""
+import os, sys, argparse
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn as nn, torch.nn.functional as F
+import pam
+from pam import _lib, hrnet_hip
+
+ap = argparse.ArgumentParser(); ap.add_argument('--n', type=int, default=20); ap.add_argument('--tiles', default='-1')
+args = ap.parse_args()
+dev = torch.device('cuda:0')
+e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); e.lib = _lib.load(); e.device = dev
+
+
+def timeit(fn, iters=30):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(True), torch.cuda.Event(True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+LAYERS = [(96, 72, 48, 48, 3, 1), (48, 36, 96, 96, 3, 1), (24, 18, 192, 192, 3, 1), (12, 9, 384, 384, 3, 1),
+          (96, 72, 64, 64, 3, 1), (96, 72, 256, 64, 1, 1), (96, 72, 64, 256, 1, 1), (192, 144, 64, 64, 3, 2), (384, 288, 8, 64, 3, 2),
+          (48, 36, 96, 48, 1, 1), (96, 72, 48, 96, 3, 2), (12, 9, 384, 48, 1, 1)]
+for (h, w, cin, cout, k, s) in LAYERS:
+    conv = nn.Conv2d(cin, cout, k, s, k // 2, bias=True)
+    op = hrnet_hip.PackedConv(conv, dev)
+    x = torch.randn((args.n, cin, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    ho, wo = (h + 2 * (k // 2) - k) // s + 1, (w + 2 * (k // 2) - k) // s + 1
+    fl = 2.0 * args.n * ho * wo * cout * cin * k * k
+    mi = conv.to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        t_mi = timeit(lambda: torch.relu(mi(x)))
+    line = '%3dx%-3d %3d->%-3d k%d s%d  %6.2f GF  miopen+relu %7.1f us (%6.1f TF/s) |' % (h, w, cin, cout, k, s, fl / 1e9, t_mi, fl / t_mi / 1e6)
+    for t in [int(q) for q in args.tiles.split(',')]:
+        e.tile_cfg = t
+        try:
+            us = timeit(lambda: e.conv(op, x, relu=True))
+            line += ' cfg%d %7.1f us (%6.1f TF/s)' % (t, us, fl / us / 1e6)
+        except Exception as ex:
+            line += ' cfg%d n/a' % t
+    print(line, flush=True)

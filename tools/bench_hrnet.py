@@ -9,7 +9,8 @@ from pam import hrnet
 ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, default=20)
 ap.add_argument('--iters', type=int, default=10)
-ap.add_argument('--modes', default='eager,bench,graph')
+ap.add_argument('--modes', default='graph')
+ap.add_argument('--backends', default='hip,miopen')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 flops = hrnet.count_flops() * args.n
@@ -27,13 +28,14 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-for mode in args.modes.split(','):
-    torch.backends.cudnn.benchmark = (mode != 'eager')
+for backend in args.backends.split(','):
+  for mode in args.modes.split(','):
+    torch.backends.cudnn.benchmark = (mode == 'bench')
     t0 = time.time()
-    net = hrnet.HRNetPose(48, 17, None, use_graph=(mode == 'graph'))
+    net = hrnet.HRNetPose(48, 17, None, use_graph=(mode == 'graph'), backend=backend)
     x = net.input_buffer(args.n)
     x.copy_(torch.randn(x.shape, device=dev).to(x.dtype))
     net.heatmaps(x); torch.cuda.synchronize()
     t1 = time.time()
     ms = timeit(lambda: net.heatmaps(x), args.iters)
-    print('%-6s N=%d  first-call %.1fs  %.3f ms/forward  %.1f TFLOP/s' % (mode, args.n, t1 - t0, ms, flops / ms / 1e9), flush=True)
+    print(backend, '%-6s N=%d  first-call %.1fs  %.3f ms/forward  %.1f TFLOP/s' % (mode, args.n, t1 - t0, ms, flops / ms / 1e9), flush=True)
