@@ -2,7 +2,7 @@
 """Headline benchmark: end-to-end multi-view frames/s of the per-frame hot path on synthetic Shelf-like frames
 (5 cameras, 1032x776, 4 persons -> 20 person crops per frame):
 
-    crop/resize/normalise (HIP) -> HRNet-W48 384x288 conv stack (PyTorch-ROCm bf16, hipGraph) -> heat-map decode (HIP)
+    crop/resize/normalise (HIP) -> HRNet-W48 384x288 conv stack (hand-written MFMA HIP kernels, bf16, hipGraph) -> heat-map decode (HIP)
     -> [one all-gather of per-view keypoints when views are sharded over ranks] -> fused tracker frame kernel (HIP):
     association + part-aware epipolar view filter + weighted DLT + smoothing + hypothesis initialisation.
 
@@ -159,8 +159,8 @@ def main():
             'config': {'workload': 'Shelf-like %s: %d cams %dx%d, %d persons, %d crops/frame 384x288, 17 joints'
                                    % (size, C, fw, fh, P, int(np.median(crops_per_frame))),
                        'views_per_rank': [len(p) for p in pipe.gather.parts], 'tracker': 'fused HIP frame kernel (f64)',
-                       'hrnet_weights': pipe.net.weights if pipe.net else None, 'exchange': 'all_gather per frame' if world > 1 else 'none'},
-            'roofline': {'kernel': 'HRNet-W48 conv stack (hipGraph replay, %d crops)' % int(np.median([n for n in local_crops[W:] if n > 0] or [0])),
+                       'hrnet_weights': pipe.net.weights if pipe.net else None, 'conv_backend': pipe.net.backend if pipe.net else None, 'exchange': 'all_gather per frame' if world > 1 else 'none'},
+            'roofline': {'kernel': 'HRNet-W48 conv stack: k_conv3x3 / k_conv_igemm MFMA kernels (hipGraph replay, %d crops)' % int(np.median([n for n in local_crops[W:] if n > 0] or [0])),
                          'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': avg_ms,
                          'flops_per_crop': flops_crop},

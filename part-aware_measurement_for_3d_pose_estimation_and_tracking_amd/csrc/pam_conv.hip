@@ -224,28 +224,58 @@ static int dispatch_conv(hipStream_t s, const ConvArgs& a, int force) {
 // ====================================================================================================================
 struct C3Args {
     const uint16_t* in; const uint16_t* w; const float* bias; const uint16_t* res; uint16_t* out;
-    int N, H, W, Cout, Kpad, TH, TW, tiles_x, tiles_y, relu;
+    int N, H, W, Cout, Kpad, TH, TW, tiles_x, tiles_y, relu, dbg;
 };
+
+__host__ __device__ constexpr int c3_maxpatch(int nwaves) { return nwaves == 1 ? 112 : nwaves == 2 ? 192 : nwaves == 3 ? 272 : 352; }
 
 template <int CIN, int NTW, int NWAVES>
 __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
-    constexpr int T = 64 * NWAVES;
-    constexpr int CC = (CIN <= 96) ? CIN : 96;          // channels per resident patch chunk
-    constexpr int NCH = CIN / CC;
-    constexpr int PITCH = CC * 2 + 16;                  // bytes per patch pixel (16-B pad: ds_read_b128 bank spread)
-    constexpr int C8 = CC / 8;
+    constexpr int T = 64 * NWAVES, BN = 16 * NTW;
+    constexpr int CK = (CIN == 48) ? 48 : 32;           // input channels per resident chunk
+    constexpr int NCHUNK = CIN / CK, PC8 = CK / 8;
+    constexpr int PITCH_A = CK * 2 + 16;                // bytes per patch pixel   (pad: conflict-free ds_read_b128)
+    constexpr int PITCH_W = 9 * CK * 2 + 16;            // bytes per weight row    (9 taps x CK channels of one cout)
+    constexpr int NPP = (c3_maxpatch(NWAVES) * PC8 + T - 1) / T;    // patch pieces per thread per chunk
+    constexpr int NWQ = BN * 9 * PC8;                                // weight pieces per chunk
+    constexpr int NWP = (NWQ + T - 1) / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int bx = blockIdx.x;
     const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, n = bx / (a.tiles_x * a.tiles_y);
     const int ty0 = ty * a.TH, tx0 = tx * a.TW;
     const int PW = a.TW + 2, PH = a.TH + 2, npatch = PW * PH, npx = a.TH * a.TW;
-    const int n0 = blockIdx.y * 16 * NTW;
+    const int n0 = blockIdx.y * BN;
+    char* Wsm = smem + (((size_t)npatch * PITCH_A + 15) & ~(size_t)15);
+    char* zero_slot = Wsm + (size_t)BN * PITCH_W;       // 48 zero bytes: K-tail A lanes + slack behind the last weight row
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * CIN * 2), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Cout * a.Kpad * 2), 0x00020000);
-    char* zero_slot = smem + (size_t)npatch * PITCH;   // 16 zero bytes for K-tail lanes
-    if (tid == 0) *(u32x4*)zero_slot = (u32x4){0, 0, 0, 0};
+    if (tid < 3) *(u32x4*)(zero_slot + tid * 16) = (u32x4){0, 0, 0, 0};
+    if (CIN == 48 && tid < BN) *(u32x4*)(Wsm + (size_t)tid * PITCH_W + 9 * CK * 2) = (u32x4){0, 0, 0, 0};   // row pads feed the K tail
 
+    // ---- per-thread piece descriptors (fixed over the chunk loop) ------------------------------------------------------
+    unsigned goffA[NPP], goffW[NWP];
+#pragma unroll
+    for (int i = 0; i < NPP; ++i) {
+        const int q = tid + i * T;
+        goffA[i] = OOB_OFFSET;
+        if (q < npatch * PC8) {
+            const int pp = q / PC8, c8 = q - pp * PC8;
+            const int pyy = pp / PW, pxx = pp - pyy * PW;
+            const int iy = ty0 - 1 + pyy, ix = tx0 - 1 + pxx;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                goffA[i] = (unsigned)((((size_t)n * a.H + iy) * a.W + ix) * CIN * 2 + c8 * 16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+        const int w = tid + i * T;
+        goffW[i] = OOB_OFFSET;
+        if (w < NWQ) {
+            const int co = w / (9 * PC8), r = w - co * (9 * PC8), t = r / PC8, c8 = r - t * PC8;
+            goffW[i] = (unsigned)(((size_t)(n0 + co) * a.Kpad + t * CIN + c8 * 8) * 2);
+        }
+    }
     // LDS byte offset of each of this lane's 4 output-pixel slots (window corner in the haloed patch)
     unsigned lanebase[4];
 #pragma unroll
@@ -253,11 +283,32 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
         int p = wave * 64 + i * 16 + (lane & 15);
         if (p >= npx) p = 0;
         const int py = p / a.TW, px = p - py * a.TW;
-        lanebase[i] = (unsigned)((py * PW + px) * PITCH);
+        lanebase[i] = (unsigned)((py * PW + px) * PITCH_A);
     }
-    unsigned wrow[NTW];
+
+    u32x4 ra[NPP], rw[NWP];
+    auto gload = [&](int cc) {
+        const unsigned so = (unsigned)(cc * CK * 2);
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) wrow[j] = (unsigned)(((size_t)(n0 + j * 16 + (lane & 15)) * a.Kpad + 8 * g) * 2);
+        for (int i = 0; i < NPP; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, goffA[i], goffA[i] == OOB_OFFSET ? 0 : so, 0);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, goffW[i], goffW[i] == OOB_OFFSET ? 0 : so, 0);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPP; ++i) {
+            const int q = tid + i * T;
+            if (q < npatch * PC8) { const int pp = q / PC8, c8 = q - pp * PC8; *(u32x4*)(smem + (size_t)pp * PITCH_A + c8 * 16) = ra[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int w = tid + i * T;
+            if (w < NWQ) {
+                const int co = w / (9 * PC8), r = w - co * (9 * PC8), t = r / PC8, c8 = r - t * PC8;
+                *(u32x4*)(Wsm + (size_t)co * PITCH_W + (t * CK + c8 * 8) * 2) = rw[i];
+            }
+        }
+    };
 
     f32x4 acc[4][NTW];
 #pragma unroll
@@ -265,66 +316,51 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int cc = 0; cc < NCH; ++cc) {
+    const char* wl = Wsm + (size_t)(lane & 15) * PITCH_W;               // this lane's weight row inside each 16-row N tile
+    if (!(a.dbg & 1)) gload(0);
+    for (int cc = 0; cc < NCHUNK; ++cc) {
         if (cc > 0) __syncthreads();                    // every wave is done reading the previous chunk
-        // ---- patch load: one lane per patch pixel, C8 16-byte pieces each -------------------------------------------
-        for (int pp = tid; pp < npatch; pp += T) {
-            const int pyy = pp / PW, pxx = pp - pyy * PW;
-            const int iy = ty0 - 1 + pyy, ix = tx0 - 1 + pxx;
-            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned goff = ok ? (unsigned)((((size_t)n * a.H + iy) * a.W + ix) * CIN * 2 + cc * CC * 2) : OOB_OFFSET;
-            u32x4 v[C8];
-#pragma unroll
-            for (int q = 0; q < C8; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? goff + q * 16 : OOB_OFFSET, 0, 0);
-#pragma unroll
-            for (int q = 0; q < C8; ++q) *(u32x4*)(smem + (size_t)pp * PITCH + q * 16) = v[q];
-        }
+        lstore();
         __syncthreads();
-
-        // ---- K loop over (tap, 32-channel step) of this chunk; B fragments one step ahead in registers --------------
-        constexpr int KS = (CIN == 48) ? 1 : CC / 32;
-        constexpr int NSTEP = (CIN == 48) ? 14 : 9 * KS;
-        auto astep_off = [&](int s, unsigned& aoff, bool& zero) {      // per-lane LDS offset (relative to lanebase) of step s
-            if constexpr (CIN == 48) {
-                const int k0 = 32 * s + 8 * g;                          // flattened (tap, c) index; a slice never straddles taps
+        if (cc + 1 < NCHUNK && !(a.dbg & 1)) gload(cc + 1);             // next chunk in flight under the MFMAs below
+        if (a.dbg & 2) continue;
+        if constexpr (CIN == 48) {
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                const int k0 = 32 * s + 8 * g;                           // flattened (tap, c); an 8-slice never straddles taps
                 const int t = k0 / 48, c = k0 - t * 48;
                 const int ky = t / 3, kx = t - ky * 3;
-                zero = k0 >= 432;
-                aoff = (unsigned)((ky * PW + kx) * PITCH + c * 2);
-            } else {
-                const int t = s / KS, ks = s - t * KS;
+                const bool zero = k0 >= 432;
+                const unsigned aoff = (unsigned)((ky * PW + kx) * PITCH_A + c * 2);
+                bf16x8 af[4], bfr[NTW];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(zero ? zero_slot : smem + lanebase[i] + aoff);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) bfr[j] = *(const bf16x8*)(wl + (size_t)j * 16 * PITCH_W + k0 * 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                           __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
                 const int ky = t / 3, kx = t - ky * 3;
-                zero = false;
-                aoff = (unsigned)((ky * PW + kx) * PITCH + ks * 64 + g * 16);
+                const unsigned aoff = (unsigned)((ky * PW + kx) * PITCH_A + g * 16);
+                bf16x8 af[4], bfr[NTW];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(smem + lanebase[i] + aoff);
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) bfr[j] = *(const bf16x8*)(wl + (size_t)j * 16 * PITCH_W + t * 64 + g * 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
+                                                                           __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
             }
-        };
-        auto wstep_off = [&](int s) -> unsigned {                       // byte offset along K of step s in the packed weights
-            if constexpr (CIN == 48) return (unsigned)(s * 64);
-            else { const int t = s / KS, ks = s - t * KS; return (unsigned)((t * CIN + cc * CC + ks * 32) * 2); }
-        };
-        u32x4 bcur[NTW], bnxt[NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) bcur[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wrow[j], wstep_off(0), 0);
-#pragma unroll 2
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s + 1 < NSTEP) {
-                const unsigned wo = wstep_off(s + 1);
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) bnxt[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wrow[j], wo, 0);
-            }
-            unsigned aoff; bool zero;
-            astep_off(s, aoff, zero);
-            bf16x8 af[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(zero ? zero_slot : smem + lanebase[i] + aoff);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                       __builtin_bit_cast(bf16x8_t, bcur[j]), acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) bcur[j] = bnxt[j];
         }
     }
     __syncthreads();
@@ -342,6 +378,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     }
     __syncthreads();
     constexpr int PPX = 2 * NTW;
+    if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)Ew[0]; return; }
 #pragma unroll
     for (int t = 0; t < PPX; ++t) {
         const int q = lane + 64 * t;
@@ -371,7 +408,6 @@ template <int CIN, int NTW>
 static int launch_c3(hipStream_t s, const C3Args& a, int nwaves, size_t lds) {
     dim3 grid(a.tiles_x * a.tiles_y * a.N, a.Cout / (16 * NTW));
     switch (nwaves) {
-        case 1: hipLaunchKernelGGL((k_conv3x3<CIN, NTW, 1>), grid, dim3(64), lds, s, a); break;
         case 2: hipLaunchKernelGGL((k_conv3x3<CIN, NTW, 2>), grid, dim3(128), lds, s, a); break;
         case 3: hipLaunchKernelGGL((k_conv3x3<CIN, NTW, 3>), grid, dim3(192), lds, s, a); break;
         case 4: hipLaunchKernelGGL((k_conv3x3<CIN, NTW, 4>), grid, dim3(256), lds, s, a); break;
@@ -380,27 +416,31 @@ static int launch_c3(hipStream_t s, const C3Args& a, int nwaves, size_t lds) {
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
-// choose the spatial tile: divisors of H, W; prefer full MFMA rows, enough workgroups to fill 256 CUs, small halo
+// choose the spatial tile: divisors of H, W; >= 2 waves (the block's waves share the staged weights), prefer full MFMA
+// rows, enough workgroups to fill 256 CUs, big tiles (fewer weight re-fetches) and small halo
 static bool pick_tile(int N, int H, int W, int Cin, int Cout, int ntw, int& TH, int& TW, int& nwaves, size_t& lds) {
-    const int CC = Cin <= 96 ? Cin : 96;
-    const int pitch = CC * 2 + 16;
+    const int CK = Cin == 48 ? 48 : 32;
+    const int pitch_a = CK * 2 + 16, pitch_w = 9 * CK * 2 + 16, bn = 16 * ntw;
     double best = -1;
     for (int th = 1; th <= H; ++th) {
         if (H % th) continue;
         for (int tw = 1; tw <= W; ++tw) {
             if (W % tw) continue;
             const int npx = th * tw;
-            if (npx > 256 || npx < 32) continue;
+            if (npx > 256 || npx <= 64) continue;
             const int nw = (npx + 63) / 64;
-            const size_t patch = (size_t)(th + 2) * (tw + 2) * pitch + 16;
+            const int npatch = (th + 2) * (tw + 2);
+            if (npatch > c3_maxpatch(nw)) continue;
+            const size_t main_b = (((size_t)npatch * pitch_a + 15) & ~(size_t)15) + (size_t)bn * pitch_w + 64;
             const size_t epi = (size_t)nw * 64 * (16 * ntw + 4) * 4;
-            const size_t need = patch > epi ? patch : epi;
-            if (need > 64 * 1024) continue;
+            const size_t need = main_b > epi ? main_b : epi;
+            if (need > 80 * 1024) continue;
             const double util = (double)npx / (64.0 * nw);
-            const double blocks = (double)(H / th) * (W / tw) * N * (Cout / (16 * ntw));
+            const double blocks = (double)(H / th) * (W / tw) * N * (Cout / bn);
             const double fill = blocks >= 512 ? 1.0 : blocks / 512.0;
-            const double halo = (double)npx / ((th + 2.0) * (tw + 2.0));
-            const double score = util * (0.35 + 0.65 * fill) * (0.6 + 0.4 * halo);
+            const double halo = (double)npx / npatch;
+            const double share = nw >= 3 ? 1.0 : 0.85;
+            const double score = util * (0.3 + 0.7 * fill) * (0.6 + 0.4 * halo) * share;
             if (score > best) { best = score; TH = th; TW = tw; nwaves = nw; lds = need; }
         }
     }
@@ -420,12 +460,12 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.Ktot = KH * KW * Cin; a.Kpad = (a.Ktot + KC - 1) / KC * KC; a.M = N * a.Ho * a.Wo;
     if (H >= 32768 || W >= 32768) return PAM_E_ARG;
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && tile_cfg < 0 &&
+    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&
         (Cin == 48 || Cin == 64 || Cin == 96 || Cin == 192 || Cin == 384)) {
         const int ntw = (Cout % 48 == 0) ? 3 : 4;
         C3Args c;
         c.in = a.in; c.w = a.w; c.bias = bias; c.res = a.res; c.out = a.out;
-        c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.Kpad = a.Kpad; c.relu = relu;
+        c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.Kpad = a.Kpad; c.relu = relu; c.dbg = tile_cfg >= 100 ? tile_cfg - 100 : 0;
         int nw = 0; size_t lds = 0;
         if (pick_tile(N, H, W, Cin, Cout, ntw, c.TH, c.TW, nw, lds)) {
             c.tiles_x = W / c.TW; c.tiles_y = H / c.TH;

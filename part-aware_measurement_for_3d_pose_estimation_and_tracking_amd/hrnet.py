@@ -289,7 +289,7 @@ class HRNetPose(object):
         if g is not None:
             return g[1]
         H, W = self.resolution
-        return torch.empty((n, self.in_channels, H, W), dtype=self.dtype, device=self.device).contiguous(memory_format=torch.channels_last)
+        return torch.empty((n, self.in_channels, H, W), dtype=self.dtype, device=self.device, memory_format=torch.channels_last)
 
     # -- HIP kernels around it -----------------------------------------------------------------------------------------
     def preprocess(self, frame_ptrs, frame_h, frame_w, view_of, boxes, out):

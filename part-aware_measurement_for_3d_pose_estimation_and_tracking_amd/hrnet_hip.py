@@ -71,9 +71,7 @@ class HipHRNet(object):
         assert cin == op.cin and x.is_contiguous(memory_format=torch.channels_last), (x.shape, op.cin)
         ho = (h + 2 * op.pad - op.kh) // op.stride + 1
         wo = (w + 2 * op.pad - op.kw) // op.stride + 1
-        y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device).contiguous(memory_format=torch.channels_last)
-        if op.cout == 1 or (ho == 1 and wo == 1):
-            y = y.as_strided(y.shape, (ho * wo * op.cout, 1, wo * op.cout, op.cout))
+        y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
         st = torch.cuda.current_stream(x.device).cuda_stream
         rc = self.lib.pam_conv2d_nhwc_bf16(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
                                            C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
