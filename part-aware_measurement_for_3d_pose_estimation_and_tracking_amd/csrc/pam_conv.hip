@@ -216,75 +216,63 @@ static int dispatch_conv(hipStream_t s, const ConvArgs& a, int force) {
 }
 
 // ====================================================================================================================
-// k_conv3x3: 3x3 / stride 1 / pad 1 convolutions (85 % of HRNet-W48's FLOPs) with the INPUT PATCH resident in LDS.
-// A workgroup owns a TH x TW tile of one image and one slab of 16*NTW output channels.  The (TH+2) x (TW+2) x CC input
-// patch (CC = channel chunk <= 96) is fetched ONCE (not once per tap), every MFMA A fragment is a ds_read_b128 at
-// [pixel + tap][channel slice], and the B (weight) fragments stream straight from L2 into registers one K-step ahead
-// (no weight staging, no barrier inside the K loop).
+// k_conv3x3: 3x3 / stride 1 / pad 1 convolutions (85 % of HRNet-W48's FLOPs) with the input rows resident in LDS.
+//
+// A workgroup owns TH full image rows of one image and one slab of BN = 16*NTW output channels.  Output "slots" are the
+// positions of the PADDED row-major grid (PW = W + 2 columns): slot p <-> window corner at patch pixel p, so the MFMA A
+// fragment of tap (ky,kx) is one ds_read_b128 at (p + ky*PW + kx) * PITCH_A -- linear in p, conflict-free at
+// PITCH_A = 96 B -- and the two junk columns per row are simply not stored.  K is walked in chunks of CK input channels:
+// the (TH+2) x PW x CK patch chunk and the [BN][9][CK] weight chunk (pre-packed on the host as an LDS image, so its load
+// is a linear 16-B copy) go global -> registers -> LDS, the next chunk in flight under the current chunk's MFMAs.
 // ====================================================================================================================
 struct C3Args {
-    const uint16_t* in; const uint16_t* w; const float* bias; const uint16_t* res; uint16_t* out;
-    int N, H, W, Cout, Kpad, TH, TW, tiles_x, tiles_y, relu, dbg;
+    const uint16_t* in; const uint16_t* wimg; const float* bias; const uint16_t* res; uint16_t* out;
+    int N, H, W, Cout, TH, tiles_y, relu, dbg;
+    float inv_pw;
 };
+__host__ __device__ constexpr int c3_ck(int cin) { return cin == 48 ? 48 : 32; }
+__host__ __device__ constexpr int c3_pitch_a(int) { return 96; }                         // 32 (mod 64): see tools/lds_sim.py
+__host__ __device__ constexpr int c3_pitch_w(int cin) { return cin == 48 ? 864 : 608; }
+__host__ __device__ constexpr int c3_maxpatch(int mt, int nwaves) { return 16 * mt * nwaves + 160; }
 
-__host__ __device__ constexpr int c3_maxpatch(int nwaves) { return nwaves == 1 ? 112 : nwaves == 2 ? 192 : nwaves == 3 ? 272 : 352; }
+__device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }   // exact for x < 2^16
 
-template <int CIN, int NTW, int NWAVES>
+template <int CIN, int NTW, int MT, int NWAVES>
 __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     constexpr int T = 64 * NWAVES, BN = 16 * NTW;
-    constexpr int CK = (CIN == 48) ? 48 : 32;           // input channels per resident chunk
-    constexpr int NCHUNK = CIN / CK, PC8 = CK / 8;
-    constexpr int PITCH_A = CK * 2 + 16;                // bytes per patch pixel   (pad: conflict-free ds_read_b128)
-    constexpr int PITCH_W = 9 * CK * 2 + 16;            // bytes per weight row    (9 taps x CK channels of one cout)
-    constexpr int NPP = (c3_maxpatch(NWAVES) * PC8 + T - 1) / T;    // patch pieces per thread per chunk
-    constexpr int NWQ = BN * 9 * PC8;                                // weight pieces per chunk
-    constexpr int NWP = (NWQ + T - 1) / T;
+    constexpr int CK = c3_ck(CIN), NCHUNK = CIN / CK, PC8 = CK / 8;
+    constexpr int PITCH_A = c3_pitch_a(CIN), PITCH_W = c3_pitch_w(CIN);
+    constexpr int NPP = (c3_maxpatch(MT, NWAVES) * PC8 + T - 1) / T;     // patch pieces per thread per chunk
+    constexpr int WIMG = BN * PITCH_W;                                    // bytes of one weight chunk image
+    constexpr int NWP = (WIMG / 16 + T - 1) / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int bx = blockIdx.x;
-    const int tx = bx % a.tiles_x, ty = (bx / a.tiles_x) % a.tiles_y, n = bx / (a.tiles_x * a.tiles_y);
-    const int ty0 = ty * a.TH, tx0 = tx * a.TW;
-    const int PW = a.TW + 2, PH = a.TH + 2, npatch = PW * PH, npx = a.TH * a.TW;
+    const int ty = blockIdx.x % a.tiles_y, n = blockIdx.x / a.tiles_y;
+    const int ty0 = ty * a.TH;
+    const int th = min(a.TH, a.H - ty0);                // ragged last tile
+    const int PW = a.W + 2, npatch = (th + 2) * PW, nslots = th * PW;
     const int n0 = blockIdx.y * BN;
-    char* Wsm = smem + (((size_t)npatch * PITCH_A + 15) & ~(size_t)15);
-    char* zero_slot = Wsm + (size_t)BN * PITCH_W;       // 48 zero bytes: K-tail A lanes + slack behind the last weight row
+    char* Wsm = smem + (size_t)(c3_maxpatch(MT, NWAVES)) * PITCH_A;       // fixed offset: patch region has room for junk-column reads
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * CIN * 2), 0x00020000);
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Cout * a.Kpad * 2), 0x00020000);
-    if (tid < 3) *(u32x4*)(zero_slot + tid * 16) = (u32x4){0, 0, 0, 0};
-    if (CIN == 48 && tid < BN) *(u32x4*)(Wsm + (size_t)tid * PITCH_W + 9 * CK * 2) = (u32x4){0, 0, 0, 0};   // row pads feed the K tail
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, (int)((size_t)(a.Cout / BN) * NCHUNK * WIMG), 0x00020000);
+    char* zero_slot = Wsm + WIMG;                       // 64 zero bytes: K-tail A lanes (CIN = 48) + slack behind the last weight row
+    if (tid < 4) *(u32x4*)(zero_slot + tid * 16) = (u32x4){0, 0, 0, 0};
 
-    // ---- per-thread piece descriptors (fixed over the chunk loop) ------------------------------------------------------
-    unsigned goffA[NPP], goffW[NWP];
+    // ---- per-thread patch piece descriptors (fixed over the chunk loop) -------------------------------------------------
+    unsigned goffA[NPP];
 #pragma unroll
     for (int i = 0; i < NPP; ++i) {
         const int q = tid + i * T;
         goffA[i] = OOB_OFFSET;
         if (q < npatch * PC8) {
             const int pp = q / PC8, c8 = q - pp * PC8;
-            const int pyy = pp / PW, pxx = pp - pyy * PW;
-            const int iy = ty0 - 1 + pyy, ix = tx0 - 1 + pxx;
+            const int pyy = fdiv_small(pp, a.inv_pw), pxx = pp - pyy * PW;
+            const int iy = ty0 - 1 + pyy, ix = pxx - 1;
             if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 goffA[i] = (unsigned)((((size_t)n * a.H + iy) * a.W + ix) * CIN * 2 + c8 * 16);
         }
     }
-#pragma unroll
-    for (int i = 0; i < NWP; ++i) {
-        const int w = tid + i * T;
-        goffW[i] = OOB_OFFSET;
-        if (w < NWQ) {
-            const int co = w / (9 * PC8), r = w - co * (9 * PC8), t = r / PC8, c8 = r - t * PC8;
-            goffW[i] = (unsigned)(((size_t)(n0 + co) * a.Kpad + t * CIN + c8 * 8) * 2);
-        }
-    }
-    // LDS byte offset of each of this lane's 4 output-pixel slots (window corner in the haloed patch)
-    unsigned lanebase[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int p = wave * 64 + i * 16 + (lane & 15);
-        if (p >= npx) p = 0;
-        const int py = p / a.TW, px = p - py * a.TW;
-        lanebase[i] = (unsigned)((py * PW + px) * PITCH_A);
-    }
+    const unsigned wimg0 = (unsigned)((size_t)blockIdx.y * NCHUNK * WIMG);
 
     u32x4 ra[NPP], rw[NWP];
     auto gload = [&](int cc) {
@@ -292,7 +280,10 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
 #pragma unroll
         for (int i = 0; i < NPP; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, goffA[i], goffA[i] == OOB_OFFSET ? 0 : so, 0);
 #pragma unroll
-        for (int i = 0; i < NWP; ++i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, goffW[i], goffW[i] == OOB_OFFSET ? 0 : so, 0);
+        for (int i = 0; i < NWP; ++i) {
+            const int q = tid + i * T;
+            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, q < WIMG / 16 ? (unsigned)(q * 16) : OOB_OFFSET, wimg0 + (unsigned)cc * WIMG, 0);
+        }
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -302,21 +293,22 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
         }
 #pragma unroll
         for (int i = 0; i < NWP; ++i) {
-            const int w = tid + i * T;
-            if (w < NWQ) {
-                const int co = w / (9 * PC8), r = w - co * (9 * PC8), t = r / PC8, c8 = r - t * PC8;
-                *(u32x4*)(Wsm + (size_t)co * PITCH_W + (t * CK + c8 * 8) * 2) = rw[i];
-            }
+            const int q = tid + i * T;
+            if (q < WIMG / 16) *(u32x4*)(Wsm + (size_t)q * 16) = rw[i];
         }
     };
 
-    f32x4 acc[4][NTW];
+    f32x4 acc[MT][NTW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const char* wl = Wsm + (size_t)(lane & 15) * PITCH_W;               // this lane's weight row inside each 16-row N tile
+    // slot of this lane in M tile i: p = wave*16*MT + i*16 + (lane & 15); A byte offset = p * PITCH_A (+ tap, + k slice)
+    const int p_lane = wave * 16 * MT + (lane & 15);
+    const char* al = smem + (size_t)p_lane * PITCH_A;
+    const char* wl = Wsm + (size_t)(lane & 15) * PITCH_W;
+
     if (!(a.dbg & 1)) gload(0);
     for (int cc = 0; cc < NCHUNK; ++cc) {
         if (cc > 0) __syncthreads();                    // every wave is done reading the previous chunk
@@ -332,13 +324,14 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
                 const int ky = t / 3, kx = t - ky * 3;
                 const bool zero = k0 >= 432;
                 const unsigned aoff = (unsigned)((ky * PW + kx) * PITCH_A + c * 2);
-                bf16x8 af[4], bfr[NTW];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(zero ? zero_slot : smem + lanebase[i] + aoff);
+                bf16x8 bfr[NTW];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) bfr[j] = *(const bf16x8*)(wl + (size_t)j * 16 * PITCH_W + k0 * 2);
+                bf16x8 af[MT];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(zero ? zero_slot : al + (size_t)i * 16 * PITCH_A + aoff);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
@@ -349,13 +342,14 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
             for (int t = 0; t < 9; ++t) {
                 const int ky = t / 3, kx = t - ky * 3;
                 const unsigned aoff = (unsigned)((ky * PW + kx) * PITCH_A + g * 16);
-                bf16x8 af[4], bfr[NTW];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(smem + lanebase[i] + aoff);
+                bf16x8 bfr[NTW];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) bfr[j] = *(const bf16x8*)(wl + (size_t)j * 16 * PITCH_W + t * 64 + g * 16);
+                bf16x8 af[MT];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(al + (size_t)i * 16 * PITCH_A + aoff);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
@@ -367,12 +361,12 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
 
     // ---- epilogue through LDS (fp32 + bias), then 16-byte residual loads / output stores over whole pixels ----------
     constexpr int P = 16 * NTW + 4;
-    float* Ew = (float*)smem + (size_t)wave * 64 * P;
+    float* Ew = (float*)smem + (size_t)wave * 16 * MT * P;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
         const float b = a.bias ? a.bias[n0 + j * 16 + (lane & 15)] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ew[(i * 16 + g * 4 + r) * P + j * 16 + (lane & 15)] = acc[i][j][r] + b;
     }
@@ -380,13 +374,13 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     constexpr int PPX = 2 * NTW;
     if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)Ew[0]; return; }
 #pragma unroll
-    for (int t = 0; t < PPX; ++t) {
+    for (int t = 0; t < PPX * MT / 4; ++t) {
         const int q = lane + 64 * t;
         const int slot = q / PPX, c8 = q - slot * PPX;
-        const int p = wave * 64 + slot;
-        if (p < npx) {
-            const int py = p / a.TW, px = p - py * a.TW;
-            const size_t m = ((size_t)n * a.H + ty0 + py) * a.W + tx0 + px;
+        const int p = wave * 16 * MT + slot;
+        const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
+        if (p < nslots && px < a.W) {
+            const size_t m = ((size_t)n * a.H + ty0 + py) * a.W + px;
             const f32x4 v0 = *(const f32x4*)(Ew + slot * P + c8 * 8);
             const f32x4 v1 = *(const f32x4*)(Ew + slot * P + c8 * 8 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -404,50 +398,48 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     }
 }
 
-template <int CIN, int NTW>
-static int launch_c3(hipStream_t s, const C3Args& a, int nwaves, size_t lds) {
-    dim3 grid(a.tiles_x * a.tiles_y * a.N, a.Cout / (16 * NTW));
-    switch (nwaves) {
-        case 2: hipLaunchKernelGGL((k_conv3x3<CIN, NTW, 2>), grid, dim3(128), lds, s, a); break;
-        case 3: hipLaunchKernelGGL((k_conv3x3<CIN, NTW, 3>), grid, dim3(192), lds, s, a); break;
-        case 4: hipLaunchKernelGGL((k_conv3x3<CIN, NTW, 4>), grid, dim3(256), lds, s, a); break;
-        default: return PAM_E_ARG;
-    }
+template <int CIN, int NTW, int MT, int NWAVES>
+static size_t c3_lds_bytes() {
+    const size_t main_b = (size_t)c3_maxpatch(MT, NWAVES) * c3_pitch_a(CIN) + (size_t)16 * NTW * c3_pitch_w(CIN) + 64;
+    const size_t epi = (size_t)NWAVES * 16 * MT * (16 * NTW + 4) * 4;
+    return main_b > epi ? main_b : epi;
+}
+template <int CIN, int NTW, int MT, int NWAVES>
+static int launch_c3_one(hipStream_t s, const C3Args& a) {
+    dim3 grid(a.tiles_y * a.N, a.Cout / (16 * NTW));
+    const size_t lds = c3_lds_bytes<CIN, NTW, MT, NWAVES>();
+    hipLaunchKernelGGL((k_conv3x3<CIN, NTW, MT, NWAVES>), grid, dim3(64 * NWAVES), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
-
-// choose the spatial tile: divisors of H, W; >= 2 waves (the block's waves share the staged weights), prefer full MFMA
-// rows, enough workgroups to fill 256 CUs, big tiles (fewer weight re-fetches) and small halo
-static bool pick_tile(int N, int H, int W, int Cin, int Cout, int ntw, int& TH, int& TW, int& nwaves, size_t& lds) {
-    const int CK = Cin == 48 ? 48 : 32;
-    const int pitch_a = CK * 2 + 16, pitch_w = 9 * CK * 2 + 16, bn = 16 * ntw;
-    double best = -1;
-    for (int th = 1; th <= H; ++th) {
-        if (H % th) continue;
-        for (int tw = 1; tw <= W; ++tw) {
-            if (W % tw) continue;
-            const int npx = th * tw;
-            if (npx > 256 || npx <= 64) continue;
-            const int nw = (npx + 63) / 64;
-            const int npatch = (th + 2) * (tw + 2);
-            if (npatch > c3_maxpatch(nw)) continue;
-            const size_t main_b = (((size_t)npatch * pitch_a + 15) & ~(size_t)15) + (size_t)bn * pitch_w + 64;
-            const size_t epi = (size_t)nw * 64 * (16 * ntw + 4) * 4;
-            const size_t need = main_b > epi ? main_b : epi;
-            if (need > 80 * 1024) continue;
-            const double util = (double)npx / (64.0 * nw);
-            const double blocks = (double)(H / th) * (W / tw) * N * (Cout / bn);
-            const double fill = blocks >= 512 ? 1.0 : blocks / 512.0;
-            const double halo = (double)npx / npatch;
-            const double share = nw >= 3 ? 1.0 : 0.85;
-            const double score = util * (0.3 + 0.7 * fill) * (0.6 + 0.4 * halo) * share;
-            if (score > best) { best = score; TH = th; TW = tw; nwaves = nw; lds = need; }
-        }
+// cfg = MT * 10 + NWAVES  (MT in {4, 8}; NWAVES in {2, 3, 4})
+template <int CIN, int NTW>
+static int launch_c3(hipStream_t s, const C3Args& a, int cfg) {
+    switch (cfg) {
+        case 42: return launch_c3_one<CIN, NTW, 4, 2>(s, a);
+        case 43: return launch_c3_one<CIN, NTW, 4, 3>(s, a);
+        case 44: return launch_c3_one<CIN, NTW, 4, 4>(s, a);
+        case 82: return launch_c3_one<CIN, NTW, 8, 2>(s, a);
+        case 83: return launch_c3_one<CIN, NTW, 8, 3>(s, a);
     }
-    return best > 0;
+    return PAM_E_ARG;
 }
 
-extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const float* bias,
+// choose rows per tile and the wave shape.  Measured (tools/tune_conv3x3.py): 4 M-tiles per wave beat 8, and the best
+// tile is the tallest one that fits the widest block; small images take the smallest block that holds them whole.
+static void pick_rows(int N, int H, int W, int Cout, int ntw, int& TH, int& cfg) {
+    const int PW = W + 2;
+    (void)N; (void)Cout; (void)ntw;
+    if (H * PW <= 128) { TH = H; cfg = 42; return; }
+    if (H * PW <= 192) { TH = H; cfg = 43; return; }
+    cfg = 44;
+    TH = 256 / PW;
+    if (TH < 1) TH = 1;
+    if (TH > H) TH = H;
+    // prefer a divisor of H close to the cap (no ragged last tile) when it costs < 15 % of the tile height
+    for (int t = TH; t >= 1 && t * 100 >= TH * 85; --t) if (H % t == 0) { TH = t; break; }
+}
+
+extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                                     const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
                                     int KH, int KW, int stride, int pad, int relu, int tile_cfg) {
     if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || (Cout % 48 != 0 && Cout % 64 != 0) ||
@@ -460,35 +452,41 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.Ktot = KH * KW * Cin; a.Kpad = (a.Ktot + KC - 1) / KC * KC; a.M = N * a.Ho * a.Wo;
     if (H >= 32768 || W >= 32768) return PAM_E_ARG;
-    if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&
+    if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&
         (Cin == 48 || Cin == 64 || Cin == 96 || Cin == 192 || Cin == 384)) {
         const int ntw = (Cout % 48 == 0) ? 3 : 4;
         C3Args c;
-        c.in = a.in; c.w = a.w; c.bias = bias; c.res = a.res; c.out = a.out;
-        c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.Kpad = a.Kpad; c.relu = relu; c.dbg = tile_cfg >= 100 ? tile_cfg - 100 : 0;
-        int nw = 0; size_t lds = 0;
-        if (pick_tile(N, H, W, Cin, Cout, ntw, c.TH, c.TW, nw, lds)) {
-            c.tiles_x = W / c.TW; c.tiles_y = H / c.TH;
-            hipStream_t s = (hipStream_t)stream;
-            if (ntw == 3) {
-                switch (Cin) {
-                    case 48: return launch_c3<48, 3>(s, c, nw, lds);
-                    case 64: return launch_c3<64, 3>(s, c, nw, lds);
-                    case 96: return launch_c3<96, 3>(s, c, nw, lds);
-                    case 192: return launch_c3<192, 3>(s, c, nw, lds);
-                    case 384: return launch_c3<384, 3>(s, c, nw, lds);
-                }
-            } else {
-                switch (Cin) {
-                    case 48: return launch_c3<48, 4>(s, c, nw, lds);
-                    case 64: return launch_c3<64, 4>(s, c, nw, lds);
-                    case 96: return launch_c3<96, 4>(s, c, nw, lds);
-                    case 192: return launch_c3<192, 4>(s, c, nw, lds);
-                    case 384: return launch_c3<384, 4>(s, c, nw, lds);
-                }
+        c.in = a.in; c.wimg = (const uint16_t*)w_img; c.bias = bias; c.res = a.res; c.out = a.out;
+        c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.relu = relu; c.inv_pw = 1.0f / (float)(W + 2);
+        int cfg = 0;
+        pick_rows(N, H, W, Cout, ntw, c.TH, cfg);
+        c.dbg = 0;
+        if (tile_cfg >= 100) {                           // test / tuning hook: 100 + dbg bits, or 1000 + TH*100 + cfg
+            if (tile_cfg >= 1000) { c.TH = (tile_cfg - 1000) / 100; cfg = (tile_cfg - 1000) % 100; }
+            else c.dbg = tile_cfg - 100;
+        }
+        if (c.TH * (W + 2) > 16 * (cfg / 10) * (cfg % 10)) return PAM_E_ARG;
+        c.tiles_y = (H + c.TH - 1) / c.TH;
+        hipStream_t s = (hipStream_t)stream;
+        if (ntw == 3) {
+            switch (Cin) {
+                case 48: return launch_c3<48, 3>(s, c, cfg);
+                case 64: return launch_c3<64, 3>(s, c, cfg);
+                case 96: return launch_c3<96, 3>(s, c, cfg);
+                case 192: return launch_c3<192, 3>(s, c, cfg);
+                case 384: return launch_c3<384, 3>(s, c, cfg);
+            }
+        } else {
+            switch (Cin) {
+                case 48: return launch_c3<48, 4>(s, c, cfg);
+                case 64: return launch_c3<64, 4>(s, c, cfg);
+                case 96: return launch_c3<96, 4>(s, c, cfg);
+                case 192: return launch_c3<192, 4>(s, c, cfg);
+                case 384: return launch_c3<384, 4>(s, c, cfg);
             }
         }
     }
+    if (tile_cfg >= 100) tile_cfg = -1;
     return (Cout % 48 == 0) ? dispatch_conv<3>((hipStream_t)stream, a, tile_cfg) : dispatch_conv<4>((hipStream_t)stream, a, tile_cfg);
 }
 

@@ -29,6 +29,16 @@ class PackedConv(object):
         self.bias = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(cout)).to(device).contiguous()
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.wimg = None
+        if kh == 3 and kw == 3 and self.stride == 1 and self.pad == 1 and cin in (48, 64, 96, 192, 384):
+            # per-chunk LDS images for k_conv3x3: [cout/BN][cin/CK][BN][pitch/2] bf16, row = 9 taps x CK channels (+ pad)
+            bn = 48 if cout % 48 == 0 else 64
+            ck = 48 if cin == 48 else 32
+            pitch = (864 if cin == 48 else 608) // 2
+            w5 = w.permute(0, 2, 3, 1).reshape(cout // bn, bn, 9, cin // ck, ck)        # [slab][co][tap][chunk][c]
+            img = torch.zeros((cout // bn, cin // ck, bn, pitch), dtype=torch.float32)
+            img[:, :, :, :9 * ck] = w5.permute(0, 3, 1, 2, 4).reshape(cout // bn, cin // ck, bn, 9 * ck)
+            self.wimg = img.to(torch.bfloat16).to(device).contiguous()
 
 
 class HipHRNet(object):
@@ -48,6 +58,14 @@ class HipHRNet(object):
         self.stage3 = [self._module(x) for x in m.stage3]
         self.stage4 = [self._module(x) for x in m.stage4]
         self.tile_cfg = -1
+        # concurrency: the 2-4 branches of an HR module run on side streams; the crop batch can additionally be split into
+        # `groups` independent sub-batches, each with its own stream set (the kernels are latency-bound, not chip-filling)
+        self.max_groups = 4
+        self.group_streams = [torch.cuda.Stream(device) for _ in range(self.max_groups)]
+        self.side_streams = [[torch.cuda.Stream(device) for _ in range(3)] for _ in range(self.max_groups + 1)]
+        self.side = self.side_streams[0]
+        self.multi_stream = True
+        self.groups = 1
 
     def _module(self, hm):
         P = lambda c: PackedConv(c, self.device)
@@ -74,6 +92,7 @@ class HipHRNet(object):
         y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
         st = torch.cuda.current_stream(x.device).cuda_stream
         rc = self.lib.pam_conv2d_nhwc_bf16(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
+                                           C.c_void_p(op.wimg.data_ptr()) if op.wimg is not None else None,
                                            C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
                                            C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad,
                                            1 if relu else 0, self.tile_cfg)
@@ -96,12 +115,21 @@ class HipHRNet(object):
     # -- network ------------------------------------------------------------------------------------------------------
     def _hr_module(self, mod, xs):
         xs = list(xs)
+        cur = torch.cuda.current_stream(self.device)
+        ms = self.multi_stream and len(mod['branches']) > 1
         for b, blocks in enumerate(mod['branches']):
-            x = xs[b]
-            for c1, c2 in blocks:
-                y = self.conv(c1, x, relu=True)
-                x = self.conv(c2, y, res=x, relu=True)
-            xs[b] = x
+            st = self.side[b - 1] if (ms and b > 0) else cur
+            if st is not cur:
+                st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                x = xs[b]
+                for c1, c2 in blocks:
+                    y = self.conv(c1, x, relu=True)
+                    x = self.conv(c2, y, res=x, relu=True)
+                xs[b] = x
+        if ms:
+            for b in range(1, len(mod['branches'])):
+                cur.wait_stream(self.side[b - 1])
         out = []
         for i, row in enumerate(mod['fuse']):
             ups = [(f[1], f[2], j) for j, f in enumerate(row) if f is not None and f[0] == 'up']
@@ -124,6 +152,25 @@ class HipHRNet(object):
 
     def features(self, x8):
         """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
+        g = min(self.groups, self.max_groups, x8.shape[0])
+        if g <= 1:
+            self.side = self.side_streams[0]
+            return self._features(x8)
+        cur = torch.cuda.current_stream(self.device)
+        parts = x8.chunk(g)
+        outs = []
+        for k, xp in enumerate(parts):
+            st = self.group_streams[k]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self.side = self.side_streams[k + 1]
+                outs.append(self._features(xp))
+        for k in range(len(parts)):
+            cur.wait_stream(self.group_streams[k])
+        self.side = self.side_streams[0]
+        return torch.cat(outs, dim=0)
+
+    def _features(self, x8):
         x = self.conv(self.conv1, x8, relu=True)
         x = self.conv(self.conv2, x, relu=True)
         for b in self.layer1:
