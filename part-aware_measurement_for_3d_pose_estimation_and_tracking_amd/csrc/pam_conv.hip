@@ -334,8 +334,8 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                           __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[j]),
+                                                                           __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -352,57 +352,49 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                           __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[j]),
+                                                                           __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
             }
         }
     }
-    __syncthreads();
 
-    // ---- epilogue through LDS (fp32 + bias), then 16-byte residual loads / output stores over whole pixels ----------
-    constexpr int P = 16 * NTW + 4;
-    float* Ew = (float*)smem + (size_t)wave * 16 * MT * P;
+    // ---- epilogue straight from the accumulators.  With the weights as the MFMA A operand the D tile has channels on
+    // its rows: this lane holds channels n0 + j*16 + g*4 .. +3 of pixel slot i*16 + (lane & 15) -> one 8-byte residual load
+    // and one 8-byte store per (i, j); the 4 lane groups of a pixel cover 32 contiguous bytes.
+    if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)acc[0][0][0]; return; }
+    typedef __attribute__((ext_vector_type(4))) short bf16x4;
+    f32x4 bias4[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const float b = a.bias ? a.bias[n0 + j * 16 + (lane & 15)] : 0.0f;
+    for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ew[(i * 16 + g * 4 + r) * P + j * 16 + (lane & 15)] = acc[i][j][r] + b;
-    }
-    __syncthreads();
-    constexpr int PPX = 2 * NTW;
-    if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)Ew[0]; return; }
-#pragma unroll
-    for (int t = 0; t < PPX * MT / 4; ++t) {
-        const int q = lane + 64 * t;
-        const int slot = q / PPX, c8 = q - slot * PPX;
-        const int p = wave * 16 * MT + slot;
+    for (int i = 0; i < MT; ++i) {
+        const int p = wave * 16 * MT + i * 16 + (lane & 15);
         const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
         if (p < nslots && px < a.W) {
-            const size_t m = ((size_t)n * a.H + ty0 + py) * a.W + px;
-            const f32x4 v0 = *(const f32x4*)(Ew + slot * P + c8 * 8);
-            const f32x4 v1 = *(const f32x4*)(Ew + slot * P + c8 * 8 + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const size_t o = m * a.Cout + n0 + c8 * 8;
+            const size_t o = (((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4;
+            bf16x4 rr[NTW];
             if (a.res) {
-                const bf16x8 rr = *(const bf16x8*)(a.res + o);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32((uint16_t)rr[k]);
+                for (int j = 0; j < NTW; ++j) rr[j] = *(const bf16x4*)(a.res + o + j * 16);
             }
-            bf16x8 ov;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ov[k] = (short)f32_to_bf16_rne(a.relu ? fmaxf(v[k], 0.0f) : v[k]);
-            *(bf16x8*)(a.out + o) = ov;
+            for (int j = 0; j < NTW; ++j) {
+                bf16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bias4[j][r];
+                    if (a.res) v += bf16_to_f32((uint16_t)rr[j][r]);
+                    ov[r] = (short)f32_to_bf16_rne(a.relu ? fmaxf(v, 0.0f) : v);
+                }
+                *(bf16x4*)(a.out + o + j * 16) = ov;
+            }
         }
     }
 }
 
 template <int CIN, int NTW, int MT, int NWAVES>
 static size_t c3_lds_bytes() {
-    const size_t main_b = (size_t)c3_maxpatch(MT, NWAVES) * c3_pitch_a(CIN) + (size_t)16 * NTW * c3_pitch_w(CIN) + 64;
-    const size_t epi = (size_t)NWAVES * 16 * MT * (16 * NTW + 4) * 4;
-    return main_b > epi ? main_b : epi;
+    return (size_t)c3_maxpatch(MT, NWAVES) * c3_pitch_a(CIN) + (size_t)16 * NTW * c3_pitch_w(CIN) + 64;
 }
 template <int CIN, int NTW, int MT, int NWAVES>
 static int launch_c3_one(hipStream_t s, const C3Args& a) {

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Demo driver with the reference's CLI (/root/reference/src/testmodel.py): ``python testmodel.py --dataset Shelf``.
+
+Per frame: load C images -> person boxes -> HRNet 2D poses -> PersonTrack_Project3DPose, with the reference's timing
+print-out.  YOLOv3 is outside this build: boxes (and optionally 2D poses) come from ``DATASET.PRECOMPUTED`` -- a pickle
+{frame_id: [per view list of {'bbox': [x,y,w,h], optional 'keypoints', 'keypoints_score'}]} -- see INTEGRATION.md."""
+import argparse
+import os
+import pickle
+import sys
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+import pam  # noqa: E402
+from pam.dataset import GetConfig, LoadFilenames, LoadImages  # noqa: E402
+
+
+def build_model(cfg):
+    from pam.ivclabpose import ivclabpose
+    pipe = cfg.PIPELINE_COMBINATION
+    det = cfg.DETECT_MODELS[str(pipe['DETECT_MODEL']).upper()]
+    pose_key = str(pipe['POSE_MODEL']).upper()
+    pose = cfg.POSE_MODELS[pose_key] if pose_key in cfg.POSE_MODELS else None
+    matcher = cfg.PERSON_MATCHERS[str(pipe['PERSON_MATCHER']).upper()]
+    return ivclabpose(person_detector=det, pose_detector=pose, person_matcher=matcher,
+                      conf_threshold=pipe['CONF_THRESHOLD']), pipe['BUILD_3D']
+
+
+def frame_inputs(model, precomputed, frame_id, imagelist):
+    """person_bbox_list + dump_result_list for one frame from the precomputed store (boxes, optionally 2D poses)."""
+    views = precomputed.get(frame_id, [[] for _ in imagelist])
+    pbl = [[dict(image_id=frame_id, category_id=1, score=float(p.get('score', 1.0)), bbox=list(p['bbox']),
+                 data=imagelist[v], feature=[]) for p in persons] for v, persons in enumerate(views)]
+    if all('keypoints' in p for persons in views for p in persons):
+        dump = [[dict(bbox=list(p['bbox']), keypoints=list(p['keypoints']), keypoints_score=list(p['keypoints_score']),
+                      feature=[]) for p in persons] for persons in views]
+        return pbl, dump, 0.0
+    t0 = time.time()
+    dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
+    return pbl, dump, time.time() - t0
+
+
+def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
+    dataset = cfg.DATASET
+    os.makedirs(cfg.OUTPUT, exist_ok=True)
+    with open(os.path.join(dataset.ROOT, dataset.CALIBRATION_FILE), 'rb') as f:
+        camera_parameter = pickle.load(f)
+    with open(os.path.join(dataset.ROOT, dataset.PRECOMPUTED), 'rb') as f:
+        precomputed = pickle.load(f)
+    model, build3D = build_model(cfg)
+    t_pose = t_track = 0.0
+    start, end = dataset.TEST_RANGE
+    n_views = len(dataset.FOLDERS_ORDER)
+    for i, frame_id in enumerate(range(start, end)):
+        imagelist, timestamp = LoadImages(dataset.TEST_DATASET, inputs[frame_id])
+        if i == 0:
+            model.GetCameraParameters(camera_parameter, imagelist[0].shape[0], imagelist[0].shape[1])
+        pbl, dump, dt_pose = frame_inputs(model, precomputed, frame_id, imagelist)
+        result = None
+        dt_track = 0.0
+        if any(len(v) for v in dump):                       # testmodel.py:66 guard: no pose in any view -> frame skipped
+            t0 = time.time()
+            result = model.PersonTrack_Project3DPose(frame_id=frame_id, person_bbox_list=pbl, dump_results=dump, build3D=build3D)
+            dt_track = time.time() - t0
+        if on_frame is not None:
+            on_frame(frame_id, timestamp, result)
+        if frame_id > start + 10:
+            t_pose += dt_pose
+            t_track += dt_track
+    n = max(1, end - start - 10)
+    print("Person Detect Processing time (s/f): %f" % 0.0)
+    print("Pose Detect Processing time (s/f): %f" % (t_pose / n))
+    print("Track Processing time (s/f): %f" % (t_track / n))
+    print("fps: %f" % (1 / max(1e-12, (t_pose / n) / n_views + t_track / n)))
+    print("tracking fps: %f" % (1 / max(1e-12, t_track / n)))
+
+
+if __name__ == "__main__":
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--dataset', help='Three options: CampusSeq1, Shelf, Panoptic', type=str, default='CampusSeq1')
+    opt = parser.parse_args()
+    cfg = GetConfig(os.path.join(_HERE, 'configs', opt.dataset, 'model_configs.yaml'))
+    datas = LoadFilenames(cfg.DATASET)
+    {'PersonTrack_Project3DPose': test_ivclabpose_PersonTrack_Project3DPose}[cfg.TEST_FUNCTION](cfg, datas)

@@ -1,0 +1,128 @@
+"""Host-side driver surface: PCP evaluator vs the reference's numbers (golden), config / dataset plumbing, and (GPU) the
+evalmodel.py loop on a synthetic on-disk dataset."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+import pam
+from pam import synth
+from pam.dataset import GetConfig, LoadFilenames, LoadImages, natural_key
+from pam import evaluation as E
+import golden_io as G
+
+
+def _pcp_case():
+    z = G.load('pcp_S2.npz')
+    gt = z['gt']
+    actors = [[(None if np.isnan(gt[a, f]).all() else gt[a, f]) for f in range(gt.shape[1])] for a in range(gt.shape[0])]
+    preds = {t: z['pred.%d' % t] for t in range(int(z['n_frames']))}
+    for t in z['skipped']:
+        preds[int(t)] = []
+    return z, actors, preds
+
+
+def test_pcp_matches_reference():
+    z, actors, preds = _pcp_case()
+    check, rows = E.evaluate_pcp(z['eval_ranges'].tolist(), preds, actors, verbose=False)
+    assert np.array_equal(check, z['check_result'])
+    ref_rows = z['table']
+    assert 0 < (check < 0).sum() < (check > 0).sum()             # a non-trivial case: some limbs fail
+    for r, rr in zip(rows[1:], ref_rows[1:]):
+        assert r[0] == str(rr[0])
+        for a, b in zip(r[1:], rr[1:]):
+            assert abs(float(a) - float(b)) < 1e-9, (r, rr)
+
+
+def test_coco2shelf_layout():
+    p = np.arange(51, dtype=float).reshape(3, 17)
+    s = E.coco2shelf3D(p)
+    assert s.shape == (14, 3)
+    assert np.array_equal(s[0], p[:, 16]) and np.array_equal(s[11], p[:, 9])
+    mid = (p[:, 6] + p[:, 5]) / 2
+    np.testing.assert_allclose(s[12], mid + (p[:, 0] - mid) * np.array([0.3, 0.4, 0.6]))
+
+
+def test_configs_parse_and_keys():
+    root = os.path.join(pam.PKG_DIR, 'configs')
+    ref = {'CampusSeq1': (25, 15, 15, 30, 0.6, 0.4), 'Shelf': (60, 30, 60, 70, 0.3, 0.5), 'Panoptic': (60, 50, 30, 60, 0.3, 0.4)}
+    for name, (epi, ini, jt, a2d, sig, conf) in ref.items():
+        c = GetConfig(os.path.join(root, name, 'model_configs.yaml'))
+        m = c.PERSON_MATCHERS.ITERATIVE
+        assert (m.EPI_THRESHOLD, m.INIT_THRESHOLD, m.JOINT_THRESHOLD, m.ALPHA2D, m.SIGMA) == (epi, ini, jt, a2d, sig)
+        assert c.PIPELINE_COMBINATION.CONF_THRESHOLD == conf and m.N_INIT == 3 and m.MAX_AGE == 10
+        assert c.POSE_MODELS.HRPOSE.RESOLUTION == [384, 288] and c.TEST_FUNCTION == 'PersonTrack_Project3DPose'
+        assert dict(synth.MATCHER_CFG[name], NAME='Iterative', CONF_THRESHOLD=conf).items() >= {k: v for k, v in m.items() if k in synth.MATCHER_CFG[name]}.items()
+
+
+def test_natural_sort_and_bgr(tmp_path):
+    from PIL import Image
+    names = ['img10.png', 'img2.png', 'img1.png']
+    assert sorted(names, key=natural_key) == ['img1.png', 'img2.png', 'img10.png']
+    for cam in ('Camera0', 'Camera1'):
+        os.makedirs(tmp_path / cam)
+        for i, n in enumerate(names):
+            a = np.zeros((4, 6, 3), dtype=np.uint8); a[..., 0] = 200; a[..., 2] = 10 + i     # RGB: R=200, B=10+i
+            Image.fromarray(a).save(tmp_path / cam / n)
+    ds = pam.dataset.AttrDict(dict(ROOT=str(tmp_path), FOLDERS_ORDER=['Camera0', 'Camera1'], DATA_FORMAT='*.png'))
+    files = LoadFilenames(ds)
+    assert [os.path.basename(f[0]) for f in files] == ['img1.png', 'img2.png', 'img10.png']
+    imgs, ts = LoadImages('Shelf', files[0])
+    assert ts == 'img1' and imgs[0].shape == (4, 6, 3) and imgs[0][0, 0, 0] == 12 and imgs[0][0, 0, 2] == 200   # BGR
+
+
+@pytest.mark.gpu
+def test_evalmodel_loop_on_synthetic_dataset(tmp_path, capsys):
+    """evalmodel.py's loop end to end: images on disk, calibration pickle, precomputed 2D poses -> result pickle identical to
+    the oracle's output, PCP table printed."""
+    from PIL import Image
+    import scipy.io as scio
+    from oracle import cpu_ref as O
+    from pam import evalmodel
+    seq = synth.make_sequence('S1', n_frames=40, seed=11, occlusion_every=9, empty_view_every=13, birth_death_frame=20)
+    root = tmp_path / 'CampusSeq1'
+    for c in range(3):
+        os.makedirs(root / ('Camera%d' % c))
+        for t in range(40):
+            Image.fromarray(np.zeros((8, 10, 3), dtype=np.uint8)).save(root / ('Camera%d' % c) / ('%04d.png' % t))
+    with open(root / 'camera_parameter.pickle', 'wb') as f:
+        pickle.dump(seq['calib'], f)
+    pre = {}
+    for t, views in enumerate(seq['frames']):
+        _, dr = synth.to_dump_results(views)
+        pre[t] = [[dict(bbox=d['bbox'], keypoints=d['keypoints'], keypoints_score=d['keypoints_score']) for d in v] for v in dr]
+    with open(root / 'detections.pickle', 'wb') as f:
+        pickle.dump(pre, f)
+    pids = sorted({p for w in seq['gt3d'] for p in w})
+    actor = np.empty((1, len(pids)), dtype=object)
+    for a, p in enumerate(pids):
+        fr = np.empty((40, 1), dtype=object)
+        for t in range(40):
+            fr[t, 0] = E.coco2shelf3D(seq['gt3d'][t][p].T) if p in seq['gt3d'][t] else np.zeros((0, 0))
+        actor[0, a] = fr
+    scio.savemat(str(root / 'actorsGT.mat'), {'actor3D': actor})
+    cfg = GetConfig(os.path.join(pam.PKG_DIR, 'configs', 'CampusSeq1', 'model_configs.yaml'))
+    cfg.DATASET.ROOT = str(root); cfg.DATASET.DATA_FORMAT = '*.png'; cfg.DATASET.TEST_RANGE = [0, 40]
+    cfg.DATASET.EVAL_RANGE = [[3, 40]]; cfg.OUTPUT = str(tmp_path / 'out')
+    cfg.PIPELINE_COMBINATION.POSE_MODEL = 'Precomputed'
+    evalmodel.eval_ivclabpose_PersonTrack_Project3DPose(cfg, LoadFilenames(cfg.DATASET))
+    out = capsys.readouterr().out
+    assert 'Total' in out and 'tracking fps' in out
+    with open(tmp_path / 'out' / 'CampusSeq1' / 'logs' / 'None_Precomputed_Iterative_CampusSeq1.pkl', 'rb') as f:
+        res = pickle.load(f)
+    mc = dict(synth.MATCHER_CFG['CampusSeq1']); conf = mc.pop('CONF_THRESHOLD')
+    ref = O.OracleIvclabpose(mc, conf)
+    ref.GetCameraParameters(seq['calib'])
+    n = 0
+    for t, views in enumerate(seq['frames']):
+        pbl, dr = synth.to_dump_results(views)
+        if not any(len(v) for v in dr):
+            assert len(res[t]) == 0
+            continue
+        e3 = ref.PersonTrack_Project3DPose(t, pbl, dr, 'SVD')[3]
+        assert np.asarray(res[t]).shape == np.asarray(e3).shape, t
+        if len(e3):
+            np.testing.assert_allclose(res[t], e3, rtol=0, atol=1e-5)
+            n += len(e3)
+    assert n > 30
