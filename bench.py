@@ -138,15 +138,28 @@ def main():
         elapsed = float(tt.item())
     final = pipe.results()
 
-    # dominant kernel: the HRNet conv stack (one hipGraph replay per frame), HIP events on the launch stream
+    # dominant kernel group: the HRNet conv stack (one hipGraph replay per frame = 308 launches of k_conv3x3 / k_conv_igemm /
+    # k_upsample_add), HIP events on the launch stream.  Arithmetic intensity 220 FLOP/B < the 312 FLOP/B ridge (2.5 PFLOP/s
+    # over 8 TB/s): the stack is HBM-bound at this batch, so the roofline is quoted against HBM; the MFMA view is kept beside it.
     flops_crop = hrnet_mod.count_flops()
+    work = {}
+    for n in sorted(set(local_crops[W:])):
+        if n > 0:
+            work[n] = hrnet_mod.algorithmic_work(n)
     hr_ms = [a.elapsed_time(b) for (a, b), n in zip(evs, local_crops[W:]) if n > 0]
-    hr_fl = [flops_crop * n for n in local_crops[W:] if n > 0]
+    hr_fl = [work[n]['flops'] for n in local_crops[W:] if n > 0]
+    hr_by = [work[n]['bytes'] for n in local_crops[W:] if n > 0]
     if hr_ms:
         avg_ms = float(np.mean(hr_ms))
         achieved = float(np.sum(hr_fl) / (np.sum(hr_ms) * 1e-3) / 1e12)
+        achieved_gbs = float(np.sum(hr_by) / (np.sum(hr_ms) * 1e-3) / 1e9)
     else:
-        avg_ms, achieved = 0.0, 0.0
+        avg_ms, achieved, achieved_gbs = 0.0, 0.0, 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_hrnet_hbm_traffic.json')
+    n_med = int(np.median([n for n in local_crops[W:] if n > 0] or [0]))
+    if os.path.exists(tpath) and n_med == 20:
+        traffic = json.load(open(tpath))['hbm_bytes_per_forward']      # rocprofv3 PMC passes, tools/pmc_hrnet.sh (20 crops)
 
     out = None
     if rank == 0:
@@ -160,10 +173,13 @@ def main():
                                    % (size, C, fw, fh, P, int(np.median(crops_per_frame))),
                        'views_per_rank': [len(p) for p in pipe.gather.parts], 'tracker': 'fused HIP frame kernel (f64)',
                        'hrnet_weights': pipe.net.weights if pipe.net else None, 'conv_backend': pipe.net.backend if pipe.net else None, 'exchange': 'all_gather per frame' if world > 1 else 'none'},
-            'roofline': {'kernel': 'HRNet-W48 conv stack: k_conv3x3 / k_conv_igemm MFMA kernels (hipGraph replay, %d crops)' % int(np.median([n for n in local_crops[W:] if n > 0] or [0])),
-                         'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'traffic': None, 'avg_launch_ms': avg_ms,
-                         'flops_per_crop': flops_crop},
+            'roofline': {'kernel': 'HRNet-W48 conv stack: k_conv3x3 / k_conv_igemm / k_upsample_add (hipGraph replay, %d crops, %d launches)'
+                                   % (n_med, work[n_med]['launches'] if n_med in work else 0),
+                         'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'avg_launch_ms': avg_ms,
+                         'algorithmic_bytes': work[n_med]['bytes'] if n_med in work else None,
+                         'mfma': {'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'flops': work[n_med]['flops'] if n_med in work else None}},
             'final_tracks': [t['track_id'] for t in final['tracks'] if t['emitted']],
         }
 

@@ -182,6 +182,26 @@ def count_flops(c=48, num_joints=17, h=384, w=288):
     return total[0]
 
 
+def algorithmic_work(n_crops, resolution=(384, 288)):
+    """Unique HBM bytes and FLOPs of one conv-stack forward on the HIP backend (shape-only walk on the meta device):
+    per convolution input + weights + bias [+ residual] + output, per fuse sum base + terms + output."""
+    from .hrnet_hip import HipHRNet
+
+    class _MetaLib(object):
+        def __getattr__(self, name):
+            return lambda *a, **k: 0
+    eng = HipHRNet.__new__(HipHRNet)
+    eng.lib = _MetaLib(); eng.device = torch.device('meta'); eng.tile_cfg = -1; eng.multi_stream = False; eng.groups = 1
+    eng.max_groups = 1
+    model = fold_batchnorm(PoseHighResolutionNet())
+    model.final_layer = nn.Identity()
+    HipHRNet._pack(eng, model, torch.device('meta'))
+    eng.count = dict(bytes=0, flops=0, launches=0)
+    x = torch.empty((n_crops, 8, resolution[0], resolution[1]), dtype=torch.bfloat16, device='meta').contiguous(memory_format=torch.channels_last)
+    eng._features(x)
+    return eng.count
+
+
 def fold_batchnorm(model):
     """Inference form: every (conv, BN) pair becomes one conv with bias (scale = gamma / sqrt(var + eps))."""
     def fold(conv, bn):

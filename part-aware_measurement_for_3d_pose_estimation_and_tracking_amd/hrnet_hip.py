@@ -45,6 +45,19 @@ class HipHRNet(object):
     def __init__(self, folded_model, device):
         self.lib = _lib.load()
         self.device = device
+        self._pack(folded_model, device)
+        self.tile_cfg = -1
+        # concurrency: the 2-4 branches of an HR module run on side streams; the crop batch can additionally be split into
+        # `groups` independent sub-batches, each with its own stream set (the kernels are latency-bound, not chip-filling)
+        self.max_groups = 4
+        self.group_streams = [torch.cuda.Stream(device) for _ in range(self.max_groups)]
+        self.side_streams = [[torch.cuda.Stream(device) for _ in range(3)] for _ in range(self.max_groups + 1)]
+        self.side = self.side_streams[0]
+        self.multi_stream = True
+        self.groups = 1
+        self.count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
+
+    def _pack(self, folded_model, device):
         m = folded_model
         P = lambda c, **kw: PackedConv(c, device, **kw)
         self.conv1 = P(m.conv1, pad_cin_to=8)
@@ -57,15 +70,6 @@ class HipHRNet(object):
         self.stage2 = [self._module(x) for x in m.stage2]
         self.stage3 = [self._module(x) for x in m.stage3]
         self.stage4 = [self._module(x) for x in m.stage4]
-        self.tile_cfg = -1
-        # concurrency: the 2-4 branches of an HR module run on side streams; the crop batch can additionally be split into
-        # `groups` independent sub-batches, each with its own stream set (the kernels are latency-bound, not chip-filling)
-        self.max_groups = 4
-        self.group_streams = [torch.cuda.Stream(device) for _ in range(self.max_groups)]
-        self.side_streams = [[torch.cuda.Stream(device) for _ in range(3)] for _ in range(self.max_groups + 1)]
-        self.side = self.side_streams[0]
-        self.multi_stream = True
-        self.groups = 1
 
     def _module(self, hm):
         P = lambda c: PackedConv(c, self.device)
@@ -90,6 +94,12 @@ class HipHRNet(object):
         ho = (h + 2 * op.pad - op.kh) // op.stride + 1
         wo = (w + 2 * op.pad - op.kw) // op.stride + 1
         y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        if self.count is not None:       # unique bytes this conv must move: input + weights + bias [+ residual] + output
+            self.count['bytes'] += 2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin + (y.numel() if res is not None else 0)) + 4 * op.cout
+            self.count['flops'] += 2 * y.numel() * op.kh * op.kw * op.cin
+            self.count['launches'] += 1
+        if x.device.type == 'meta':
+            return y
         st = torch.cuda.current_stream(x.device).cuda_stream
         rc = self.lib.pam_conv2d_nhwc_bf16(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
                                            C.c_void_p(op.wimg.data_ptr()) if op.wimg is not None else None,
@@ -103,6 +113,11 @@ class HipHRNet(object):
     def upsample_add(self, base, terms, shifts, relu):
         n, c, h, w = base.shape
         y = torch.empty_like(base)
+        if self.count is not None:
+            self.count['bytes'] += 2 * (2 * base.numel() + sum(t.numel() for t in terms))
+            self.count['launches'] += 1
+        if base.device.type == 'meta':
+            return y
         st = torch.cuda.current_stream(base.device).cuda_stream
         ptrs = (C.c_void_p * 3)(*[C.c_void_p(t.data_ptr()) for t in terms] + [None] * (3 - len(terms)))
         sh = (C.c_int32 * 3)(*(list(shifts) + [0] * (3 - len(shifts))))
@@ -115,11 +130,11 @@ class HipHRNet(object):
     # -- network ------------------------------------------------------------------------------------------------------
     def _hr_module(self, mod, xs):
         xs = list(xs)
-        cur = torch.cuda.current_stream(self.device)
         ms = self.multi_stream and len(mod['branches']) > 1
+        cur = torch.cuda.current_stream(self.device) if ms else None
         for b, blocks in enumerate(mod['branches']):
-            st = self.side[b - 1] if (ms and b > 0) else cur
-            if st is not cur:
+            st = self.side[b - 1] if (ms and b > 0) else None
+            if st is not None:
                 st.wait_stream(cur)
             with torch.cuda.stream(st):
                 x = xs[b]
