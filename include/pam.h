@@ -70,7 +70,8 @@ typedef struct PamOutLayout {
      * newest pose),8 history length,9 newest pose time, then order[n_views], matched_det[n_views] (index of the
      * detection matched THIS frame per camera id or -1), time2d[n_views] (per camera id), nviews[17] */
     int32_t off_order, off_matched, off_time2d, off_nviews;
-    /* float64 section: [0..3] phase clocks (s): start, after association, after update, after init;
+    /* float64 section: [0..15] in-kernel clocks (s): [0] start, [1] after association, [2] after update, [3] after init,
+     * [4..11] finer phase stamps (view selection, conflicts, DLT, success, smoothing, append, end of init, end of record);
      * then per track pose3d[17*3], velocity[17*3] */
     int32_t dbl_hdr_words;
     int32_t dbl_trk_words;

@@ -246,6 +246,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     constexpr int WIMG = BN * PITCH_W;                                    // bytes of one weight chunk image
     constexpr int NWP = (WIMG / 16 + T - 1) / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (a.dbg & 8) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     const int ty = blockIdx.x % a.tiles_y, n = blockIdx.x / a.tiles_y;
     const int ty0 = ty * a.TH;
@@ -255,8 +256,22 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     char* Wsm = smem + (size_t)(c3_maxpatch(MT, NWAVES)) * PITCH_A;       // fixed offset: patch region has room for junk-column reads
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * CIN * 2), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, (int)((size_t)(a.Cout / BN) * NCHUNK * WIMG), 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    u32x2 rres[MT][NTW];
     char* zero_slot = Wsm + WIMG;                       // 64 zero bytes: K-tail A lanes (CIN = 48) + slack behind the last weight row
     if (tid < 4) *(u32x4*)(zero_slot + tid * 16) = (u32x4){0, 0, 0, 0};
+
+    const unsigned wimg0 = (unsigned)((size_t)blockIdx.y * NCHUNK * WIMG);
+    u32x4 ra[NPP], rw[NWP];
+    auto gload_w = [&](int cc) {                        // weight chunk image: linear 16-byte copy, no descriptors
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int q = tid + i * T;
+            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, q < WIMG / 16 ? (unsigned)(q * 16) : OOB_OFFSET, wimg0 + (unsigned)cc * WIMG, 0);
+        }
+    };
+    if (!(a.dbg & 1)) gload_w(0);                       // in flight while the patch descriptors are computed
 
     // ---- per-thread patch piece descriptors (fixed over the chunk loop) -------------------------------------------------
     unsigned goffA[NPP];
@@ -272,19 +287,12 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
                 goffA[i] = (unsigned)((((size_t)n * a.H + iy) * a.W + ix) * CIN * 2 + c8 * 16);
         }
     }
-    const unsigned wimg0 = (unsigned)((size_t)blockIdx.y * NCHUNK * WIMG);
-
-    u32x4 ra[NPP], rw[NWP];
-    auto gload = [&](int cc) {
+    auto gload_a = [&](int cc) {
         const unsigned so = (unsigned)(cc * CK * 2);
 #pragma unroll
         for (int i = 0; i < NPP; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, goffA[i], goffA[i] == OOB_OFFSET ? 0 : so, 0);
-#pragma unroll
-        for (int i = 0; i < NWP; ++i) {
-            const int q = tid + i * T;
-            rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, q < WIMG / 16 ? (unsigned)(q * 16) : OOB_OFFSET, wimg0 + (unsigned)cc * WIMG, 0);
-        }
     };
+    auto gload = [&](int cc) { gload_w(cc); gload_a(cc); };
     auto lstore = [&]() {
 #pragma unroll
         for (int i = 0; i < NPP; ++i) {
@@ -309,12 +317,24 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     const char* al = smem + (size_t)p_lane * PITCH_A;
     const char* wl = Wsm + (size_t)(lane & 15) * PITCH_W;
 
-    if (!(a.dbg & 1)) gload(0);
+    if (a.dbg & 16) { if (goffA[0] == 12345u) a.out[0] = 1; return; }
+    if (!(a.dbg & 1)) gload_a(0);
     for (int cc = 0; cc < NCHUNK; ++cc) {
         if (cc > 0) __syncthreads();                    // every wave is done reading the previous chunk
-        lstore();
+        if (!(a.dbg & 32)) lstore();
         __syncthreads();
         if (cc + 1 < NCHUNK && !(a.dbg & 1)) gload(cc + 1);             // next chunk in flight under the MFMAs below
+        if (cc == NCHUNK - 1 && a.res) {                                // residual tile in flight under the last chunk's MFMAs
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int p = wave * 16 * MT + i * 16 + (lane & 15);
+                const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
+                const bool ok = p < nslots && px < a.W;
+                const unsigned o = ok ? (unsigned)(((((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4) * 2) : OOB_OFFSET;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) rres[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, o, ok ? j * 32 : 0, 0);
+            }
+        }
         if (a.dbg & 2) continue;
         if constexpr (CIN == 48) {
 #pragma unroll
@@ -372,18 +392,14 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
         const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
         if (p < nslots && px < a.W) {
             const size_t o = (((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4;
-            bf16x4 rr[NTW];
-            if (a.res) {
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) rr[j] = *(const bf16x4*)(a.res + o + j * 16);
-            }
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 bf16x4 ov;
+                const bf16x4 rr = __builtin_bit_cast(bf16x4, rres[i][j]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + bias4[j][r];
-                    if (a.res) v += bf16_to_f32((uint16_t)rr[j][r]);
+                    if (a.res) v += bf16_to_f32((uint16_t)rr[r]);
                     ov[r] = (short)f32_to_bf16_rne(a.relu ? fmaxf(v, 0.0f) : v);
                 }
                 *(bf16x4*)(a.out + o + j * 16) = ov;

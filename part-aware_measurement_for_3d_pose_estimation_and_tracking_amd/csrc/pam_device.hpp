@@ -26,8 +26,9 @@ __device__ __forceinline__ void project_point(const float* __restrict__ P, doubl
     double h0 = (double)P[0] * X + (double)P[1] * Y + (double)P[2] * Z + (double)P[3];
     double h1 = (double)P[4] * X + (double)P[5] * Y + (double)P[6] * Z + (double)P[7];
     double h2 = (double)P[8] * X + (double)P[9] * Y + (double)P[10] * Z + (double)P[11];
-    u = h0 / h2;
-    v = h1 / h2;
+    const double ih = 1.0 / h2;            // one fp64 division instead of two (<= 1 ulp from numpy's h0/h2, h1/h2)
+    u = h0 * ih;
+    v = h1 * ih;
 }
 
 // ---- a3+a4: track <-> detection affinity for one (track, detection) pair, IterativeTracker.py:137-149 -----------
@@ -36,12 +37,13 @@ __device__ inline double track_det_affinity(const float* __restrict__ P, const d
                                             const double* __restrict__ det, double alpha_dt, double exp_ldt, int gate) {
     double sum = 0.0;
     int cnt = 0;
+    const double inv_alpha_dt = 1.0 / alpha_dt;
     for (int j = 0; j < J; ++j) {
         double u, v;
         project_point(P, pose3d[j * 3 + 0], pose3d[j * 3 + 1], pose3d[j * 3 + 2], u, v);
         double dy = v - det[j * 3 + 0];
         double dx = u - det[j * 3 + 1];
-        double c = 1.0 - sqrt(dy * dy + dx * dx) / alpha_dt;
+        double c = 1.0 - sqrt(dy * dy + dx * dx) * inv_alpha_dt;
         if (c > 0.0) { sum += c; ++cnt; }
     }
     double aff = (cnt > gate) ? sum / (double)cnt : 0.0;
@@ -137,12 +139,12 @@ __device__ __forceinline__ double epi_directed(const float* __restrict__ Fij, do
     double l0 = (double)Fij[0] * xi + (double)Fij[3] * yi + (double)Fij[6];
     double l1 = (double)Fij[1] * xi + (double)Fij[4] * yi + (double)Fij[7];
     double l2 = (double)Fij[2] * xi + (double)Fij[5] * yi + (double)Fij[8];
-    double nu = sqrt(l0 * l0 + l1 * l1);
-    if (nu == 0.0) nu = 1.0;
-    l0 /= nu; l1 /= nu; l2 /= nu;
-    double nrm = l0 * l0 + l1 * l1;
-    if (nrm == 0.0) nrm = 1.0;
-    return fabs(xj * l0 + yj * l1 + l2) / sqrt(nrm);
+    // matching.py:141-146 normalises the line (l /= nu, nu = 0 -> 1) and then divides the dot product by the norm of the
+    // normalised line again (= 1 to within an ulp).  One division by nu gives the same value to ~1e-16 relative at a third of
+    // the fp64 sqrt/div cost; the parity tests bound the difference at 1e-9.
+    const double s2 = l0 * l0 + l1 * l1;
+    const double inv_nu = (s2 == 0.0) ? 1.0 : rsqrt(s2);
+    return fabs(xj * l0 + yj * l1 + l2) * inv_nu;
 }
 // symmetric distance between view a (camera ca, point pa=(y,x,.)) and view b; 0 for the same camera (matching.py:133-134)
 __device__ __forceinline__ double epi_sym(const CamSet& cs, int ca, const double* pa, int cb, const double* pb) {
@@ -189,12 +191,12 @@ __device__ inline double ray_point_dist(const float* __restrict__ RK, const doub
     double dx = (double)RK[0] * x + (double)RK[1] * y + (double)RK[2];
     double dy = (double)RK[3] * x + (double)RK[4] * y + (double)RK[5];
     double dz = (double)RK[6] * x + (double)RK[7] * y + (double)RK[8];
-    double n = sqrt(dx * dx + dy * dy + dz * dz);
-    dx /= n; dy /= n; dz /= n;
+    const double in_ = rsqrt(dx * dx + dy * dy + dz * dz);
+    dx *= in_; dy *= in_; dz *= in_;
     double ex = (pos[0] + dx) - pos[0], ey = (pos[1] + dy) - pos[1], ez = (pos[2] + dz) - pos[2];
     double wx = pos[0] - Xp[0], wy = pos[1] - Xp[1], wz = pos[2] - Xp[2];
     double cx = ey * wz - ez * wy, cy = ez * wx - ex * wz, cz = ex * wy - ey * wx;
-    return sqrt(cx * cx + cy * cy + cz * cz) / sqrt(ex * ex + ey * ey + ez * ez);
+    return sqrt(cx * cx + cy * cy + cz * cz) * rsqrt(ex * ex + ey * ey + ez * ez);
 }
 
 // ---- a8/a16: greedy per-joint view filter, matching.py:243-295 --------------------------------------------------
@@ -256,9 +258,10 @@ __device__ __forceinline__ void givens_fold_row(double R[4][4], double r[4]) {
         const double b = r[k];
         if (b != 0.0) {
             const double a = R[k][k];
-            const double h = sqrt(a * a + b * b);
-            const double c = a / h, s = b / h;
-            R[k][k] = h;
+            const double h2 = a * a + b * b;
+            const double ih = rsqrt(h2);
+            const double c = a * ih, s = b * ih;
+            R[k][k] = h2 * ih;
 #pragma unroll
             for (int m = k + 1; m < 4; ++m) {
                 const double t = R[k][m];
@@ -270,7 +273,9 @@ __device__ __forceinline__ void givens_fold_row(double R[4][4], double r[4]) {
 }
 __device__ inline void min_right_singular_vector(double W[4][4], double out[4]) {
     double E[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-    for (int sweep = 0; sweep < 30; ++sweep) {
+    // columns are orthogonal to working precision once |<wp,wq>| <= 1e-15 |wp||wq|; quadratic convergence gets there in 5-7
+    // sweeps (a tighter bound sits below the rounding noise of the dot products and never triggers)
+    for (int sweep = 0; sweep < 12; ++sweep) {
         int rotated = 0;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -279,10 +284,12 @@ __device__ inline void min_right_singular_vector(double W[4][4], double out[4]) 
                 double al = 0.0, be = 0.0, ga = 0.0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { al += W[i][p] * W[i][p]; be += W[i][q] * W[i][q]; ga += W[i][p] * W[i][q]; }
-                if (ga != 0.0 && fabs(ga) > 1e-16 * sqrt(al * be)) {
-                    const double zeta = (be - al) / (2.0 * ga);
-                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                if (ga != 0.0 && ga * ga > 1e-30 * (al * be)) {
+                    // tan of the rotation angle: t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (be - al) / (2 ga), written
+                    // with one sqrt, one division and one rsqrt
+                    const double df = be - al, g2 = 2.0 * ga;
+                    const double t = copysign(1.0, df * g2) * fabs(g2) / (fabs(df) + sqrt(df * df + g2 * g2));
+                    const double c = rsqrt(1.0 + t * t), s = c * t;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const double wp = W[i][p], wq = W[i][q];
@@ -308,16 +315,12 @@ __device__ inline void min_right_singular_vector(double W[4][4], double out[4]) 
 }
 
 // one joint: views listed in sel_cid[0..V) with ages T -> weight w_t[T]; keep = bitmask over the V list positions;
-// pose(v) returns the (y,x,score) row of list position v for this joint
+// pose(v) returns the (y,x,score) row of list position v for this joint.  dlt_fold folds the kept views v = v0, v0+vstep, ...
+// into the triangular factor R (so several lanes can share one joint); dlt_merge folds another partial factor in.
 template <typename PoseFn>
-__device__ inline void dlt_joint(const CamSet& cs, int V, const int* sel_cid, const int* sel_T, const double* w_t,
-                                 double lambda_t, uint32_t keep, PoseFn pose, double out[3]) {
-    double R[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) R[r][c] = 0.0;
-    for (int v = 0; v < V; ++v) {
+__device__ inline void dlt_fold(const CamSet& cs, int V, int v0, int vstep, const int* sel_cid, const int* sel_T, const double* w_t,
+                                double lambda_t, uint32_t keep, PoseFn pose, double R[4][4]) {
+    for (int v = v0; v < V; v += vstep) {
         if (!((keep >> v) & 1u)) continue;
         const float* P = cs.P + (size_t)sel_cid[v] * 12;
         const double* p = pose(v);
@@ -330,14 +333,41 @@ __device__ inline void dlt_joint(const CamSet& cs, int V, const int* sel_cid, co
             double r1 = xy[h] * (double)P[9] - (double)P[4 * h + 1];
             double r2 = xy[h] * (double)P[10] - (double)P[4 * h + 2];
             double r3 = xy[h] * (double)P[11] - (double)P[4 * h + 3];
-            const double n = sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
-            double rr[4] = {w * (r0 / n), w * (r1 / n), w * (r2 / n), w * (r3 / n)};
+            const double wn = w * rsqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+            double rr[4] = {wn * r0, wn * r1, wn * r2, wn * r3};
             givens_fold_row(R, rr);
         }
     }
+}
+__device__ inline void dlt_zero(double R[4][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) R[r][c] = 0.0;
+}
+// packed upper triangle <-> R
+__device__ inline void dlt_pack(const double R[4][4], double* o) {
+    o[0] = R[0][0]; o[1] = R[0][1]; o[2] = R[0][2]; o[3] = R[0][3]; o[4] = R[1][1]; o[5] = R[1][2]; o[6] = R[1][3];
+    o[7] = R[2][2]; o[8] = R[2][3]; o[9] = R[3][3];
+}
+__device__ inline void dlt_merge(double R[4][4], const double* o) {
+    double r0[4] = {o[0], o[1], o[2], o[3]}; givens_fold_row(R, r0);
+    double r1[4] = {0.0, o[4], o[5], o[6]}; givens_fold_row(R, r1);
+    double r2[4] = {0.0, 0.0, o[7], o[8]}; givens_fold_row(R, r2);
+    double r3[4] = {0.0, 0.0, 0.0, o[9]}; givens_fold_row(R, r3);
+}
+__device__ inline void dlt_solve(double R[4][4], double out[3]) {
     double X[4];
     min_right_singular_vector(R, X);
     out[0] = X[0] / X[3]; out[1] = X[1] / X[3]; out[2] = X[2] / X[3];
+}
+template <typename PoseFn>
+__device__ inline void dlt_joint(const CamSet& cs, int V, const int* sel_cid, const int* sel_T, const double* w_t,
+                                 double lambda_t, uint32_t keep, PoseFn pose, double out[3]) {
+    double R[4][4];
+    dlt_zero(R);
+    dlt_fold(cs, V, 0, 1, sel_cid, sel_T, w_t, lambda_t, keep, pose, R);
+    dlt_solve(R, out);
 }
 
 // ---- a12: last sample of scipy gaussian_filter1d(mode='reflect'), IterativeTracker.py:371-383 -------------------

@@ -86,31 +86,53 @@ struct Scratch {
     uint32_t* keep; int* nview; int* ok;   // [MAXT][17], [MAXT][17], [MAXT]
     uint32_t* h_conf; float* h_sum;        // [MAXH][17][C]
     uint32_t* h_keep; double* h_pose; int* h_slot;   // [MAXH][17], [MAXH][51], [MAXH]
+    double* rpart;                  // [MAXT][17][4][10] partial triangular factors of the split DLT
 };
-__host__ __device__ inline char* carve_ws(char* base, const Dims& d, Scratch& w) {
+// small, latency-critical arrays first (they are carved out of LDS when they fit: the serial LSAP walks, atomically built
+// conflict masks and every index-chasing read then cost an LDS access instead of an L2 round trip), bulk arrays after
+__host__ __device__ inline char* carve_ws_hot(char* base, const Dims& d, Scratch& w) {
     Carver c{base};
-    w.misc = c.take<int>(8);
-    w.dt = c.take<int>(d.MAXT);
     w.aff = c.take<double>((size_t)d.C * d.MAXT * d.MAXP);
     w.lsap1 = c.bytes((size_t)d.C * ((lsap_scratch_bytes(d.N1) + 7) & ~(size_t)7));
+    w.misc = c.take<int>(8);
+    w.dt = c.take<int>(d.MAXT);
     w.as_rows = c.take<int>((size_t)d.C * d.N1); w.as_cols = c.take<int>((size_t)d.C * d.N1);
     w.match_det = c.take<int>((size_t)d.MAXT * d.C);
-    w.taken = c.take<unsigned char>((size_t)d.C * d.MAXP);
     w.um_n = c.take<int>(d.C); w.um_idx = c.take<int>((size_t)d.C * d.MAXP);
+    w.sel_n = c.take<int>(d.MAXT); w.sel_cid = c.take<int>((size_t)d.MAXT * d.C); w.sel_T = c.take<int>((size_t)d.MAXT * d.C);
+    w.conf = c.take<uint32_t>((size_t)d.MAXT * J * d.C);
+    w.keep = c.take<uint32_t>((size_t)d.MAXT * J); w.nview = c.take<int>((size_t)d.MAXT * J); w.ok = c.take<int>(d.MAXT);
+    w.taken = c.take<unsigned char>((size_t)d.C * d.MAXP);
+    return c.bytes(0);
+}
+__host__ __device__ inline char* carve_ws_bulk(char* base, const Dims& d, Scratch& w) {
+    Carver c{base};
     w.hyp_size = c.take<int>(d.MAXH); w.hyp_view = c.take<int>((size_t)d.MAXH * d.C);
     w.hyp_det = c.take<int>((size_t)d.MAXH * d.C);
     w.hc_cost = c.take<double>((size_t)d.MAXH * d.MAXP);
     w.hc_veto = c.take<unsigned char>((size_t)d.MAXH * d.MAXP);
     w.lsap2 = c.bytes(lsap_scratch_bytes(d.N2));
     w.l2_rows = c.take<int>(d.N2); w.l2_cols = c.take<int>(d.N2);
-    w.sel_n = c.take<int>(d.MAXT); w.sel_cid = c.take<int>((size_t)d.MAXT * d.C); w.sel_T = c.take<int>((size_t)d.MAXT * d.C);
     w.pred = c.take<double>((size_t)d.MAXT * J3); w.raw3d = c.take<double>((size_t)d.MAXT * J3);
-    w.conf = c.take<uint32_t>((size_t)d.MAXT * J * d.C); w.rayd = c.take<double>((size_t)d.MAXT * J * d.C);
-    w.keep = c.take<uint32_t>((size_t)d.MAXT * J); w.nview = c.take<int>((size_t)d.MAXT * J); w.ok = c.take<int>(d.MAXT);
+    w.rayd = c.take<double>((size_t)d.MAXT * J * d.C);
     w.h_conf = c.take<uint32_t>((size_t)d.MAXH * J * d.C); w.h_sum = c.take<float>((size_t)d.MAXH * J * d.C);
     w.h_keep = c.take<uint32_t>((size_t)d.MAXH * J); w.h_pose = c.take<double>((size_t)d.MAXH * J3);
     w.h_slot = c.take<int>(d.MAXH);
+    w.rpart = c.take<double>((size_t)d.MAXT * J * 4 * 10);
     return c.bytes(0);
+}
+__host__ __device__ inline char* carve_ws(char* base, const Dims& d, Scratch& w) {
+    return carve_ws_bulk(carve_ws_hot(base, d, w), d, w);
+}
+__host__ __device__ inline size_t hot_bytes(const Dims& d) {
+    Scratch w;
+    return ((size_t)(carve_ws_hot((char*)0, d, w) - (char*)0) + 15) & ~(size_t)15;
+}
+// integer part of the scene state (everything before `vel`): contiguous, copied to LDS for the duration of a frame
+__host__ __device__ inline size_t state_int_bytes(const Dims& d) {
+    SceneState s;
+    carve_state((char*)0, d, s);
+    return (size_t)((char*)s.vel - (char*)0);
 }
 
 struct FrameArgs {
@@ -123,6 +145,7 @@ struct FrameArgs {
     int* out_i; double* out_d;
     PamOutLayout ol;
     int frame_id;
+    int hot_in_lds;
 };
 
 __device__ const int g_zeroT[PAM_MAX_VIEWS] = {0};
@@ -133,13 +156,28 @@ __device__ __forceinline__ double now_s() { return (double)__builtin_amdgcn_s_me
 // The per-frame step: IterativeTracker.tracking (IterativeTracker.py:115-180) + output collection
 // (ivclabpose.py:259-287).  One 256-thread workgroup per scene; phases separated by workgroup barriers.
 // =====================================================================================================================
-__global__ __launch_bounds__(BLOCK) void k_frame(FrameArgs A) {
+__global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
     const Dims d = A.d;
     const int C = d.C, MAXP = d.MAXP, MAXT = d.MAXT, HCAP = d.HCAP, MAXH = d.MAXH;
     const int sidx = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     SceneState st; Scratch ws;
     carve_state(A.state + (size_t)sidx * A.state_stride, d, st);
     carve_ws(A.ws + (size_t)sidx * A.ws_stride, d, ws);
+    extern __shared__ __attribute__((aligned(16))) char hot_lds[];
+    char* const st_glob = A.state + (size_t)sidx * A.state_stride;
+    const size_t st_ints = state_int_bytes(d);
+    if (A.hot_in_lds) {
+        carve_ws_hot(hot_lds, d, ws);                                   // small scratch in LDS
+        char* st_lds = hot_lds + hot_bytes(d);                          // integer scene state in LDS for this frame
+        for (size_t o = (size_t)threadIdx.x * 4; o < st_ints; o += (size_t)blockDim.x * 4) *(int*)(st_lds + o) = *(const int*)(st_glob + o);
+        const ptrdiff_t sh = st_lds - st_glob;
+#define REBASE(p) p = (int*)((char*)(p) + sh)
+        REBASE(st.hdr); REBASE(st.order); REBASE(st.track_id); REBASE(st.hits); REBASE(st.age); REBASE(st.tsu); REBASE(st.already);
+        REBASE(st.state); REBASE(st.p2d_n); REBASE(st.h_head); REBASE(st.h_len); REBASE(st.jv_V); REBASE(st.p2d_order);
+        REBASE(st.p2d_time); REBASE(st.cur_det); REBASE(st.hist_time); REBASE(st.jv_count);
+#undef REBASE
+        __syncthreads();
+    }
     const PamParams& prm = *A.prm;
     const CamSet cs = A.cs;
     const int frame = A.frame_id;
@@ -233,6 +271,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame(FrameArgs A) {
             }
         ws.sel_n[i] = (st.already[s] && n >= 2) ? n : 0;
     }
+    for (int it = tid; it < nT * J * C; it += NT) ws.conf[it] = 0u;
     for (int it = tid; it < nT * J3; it += NT) {
         const int i = it / J3, e = it % J3, s = st.order[i];
         const int newest = (st.h_head[s] + st.h_len[s] - 1) % HCAP;
@@ -241,47 +280,100 @@ __global__ __launch_bounds__(BLOCK) void k_frame(FrameArgs A) {
     }
     __syncthreads();
 
-    // ---- P4b: per-joint conflict sets of the part-aware filter (matching.py:115-151, IterativeTracker.py:345-346)
-    //           and back-projection ray distances (matching.py:254-270) ---------------------------------------------
-    for (int it = tid; it < nT * J * C; it += NT) {
-        const int i = it / (J * C), r2 = it % (J * C), j = r2 / C, r = r2 % C;
-        const int V = ws.sel_n[i];
-        if (r >= V) continue;
-        const int s = st.order[i];
-        const int cr = ws.sel_cid[i * C + r];
-        const double* pr = st.p2d_pose + ((size_t)s * C + cr) * J3 + j * 3;
-        uint32_t bits = 0;
-        for (int c = r + 1; c < V; ++c) {
-            const int cc = ws.sel_cid[i * C + c];
-            const double dsym = epi_sym(cs, cr, pr, cc, st.p2d_pose + ((size_t)s * C + cc) * J3 + j * 3);
-            if (1.0 - dsym / prm.joint_threshold < 0.0) bits |= 1u << c;
+    if (tid == 0) out_d[4] = now_s();
+    // ---- P4b: per-joint conflict sets of the part-aware filter (matching.py:115-151, IterativeTracker.py:345-346): one
+    //           lane per (track, joint, view pair r < c), bits OR-ed into the row masks; back-projection ray distances
+    //           (matching.py:254-270) one lane per (track, joint, view) ---------------------------------------------------
+    int maxV = 0;
+    for (int i = 0; i < nT; ++i) maxV = max(maxV, ws.sel_n[i]);
+    {
+        const int npair = maxV * (maxV - 1) / 2;
+        // joints fastest: the 17 lanes of one (track, view pair) share both fundamental matrices and read consecutive joints
+        for (int it = tid; it < nT * npair * J; it += NT) {
+            const int i = it / (npair * J), r2 = it % (npair * J), pq = r2 / J, j = r2 % J;
+            const int V = ws.sel_n[i];
+            // unrank pq -> (r, c), r < c < maxV (row-major over the strict upper triangle), closed form
+            const double disc = (2.0 * maxV - 1.0) * (2.0 * maxV - 1.0) - 8.0 * (double)pq;
+            int r = (int)((2.0 * maxV - 1.0 - sqrt(disc)) * 0.5);
+            while (r > 0 && r * (2 * maxV - r - 1) / 2 > pq) --r;
+            while ((r + 1) * (2 * maxV - r - 2) / 2 <= pq) ++r;
+            const int c = r + 1 + (pq - r * (2 * maxV - r - 1) / 2);
+            if (c >= V) continue;
+            const int s = st.order[i];
+            const int cr = ws.sel_cid[i * C + r], cc = ws.sel_cid[i * C + c];
+            const double dsym = epi_sym(cs, cr, st.p2d_pose + ((size_t)s * C + cr) * J3 + j * 3,
+                                        cc, st.p2d_pose + ((size_t)s * C + cc) * J3 + j * 3);
+            if (1.0 - dsym / prm.joint_threshold < 0.0) atomicOr(&ws.conf[((size_t)i * J + j) * C + r], 1u << c);
         }
-        ws.conf[((size_t)i * J + j) * C + r] = bits;
-        ws.rayd[((size_t)i * J + j) * C + r] = ray_point_dist(cs.RKINV + cr * 9, cs.pos + cr * 3, pr[1], pr[0], ws.pred + i * J3 + j * 3);
+        for (int it = tid; it < nT * J * C; it += NT) {
+            const int i = it / (J * C), r2 = it % (J * C), j = r2 / C, r = r2 % C;
+            if (r >= ws.sel_n[i]) continue;
+            const int s = st.order[i], cr = ws.sel_cid[i * C + r];
+            const double* pr = st.p2d_pose + ((size_t)s * C + cr) * J3 + j * 3;
+            ws.rayd[((size_t)i * J + j) * C + r] = ray_point_dist(cs.RKINV + cr * 9, cs.pos + cr * 3, pr[1], pr[0], ws.pred + i * J3 + j * 3);
+        }
     }
     __syncthreads();
 
-    // ---- P4c: greedy filter (matching.py:243-285) + weighted DLT (construction.py:89-114) per (track, joint) ----
-    for (int it = tid; it < nT * J; it += NT) {
-        const int i = it / J, j = it % J;
+    if (tid == 0) out_d[5] = now_s();
+    // ---- P4c: greedy filter (matching.py:243-285) + weighted DLT (construction.py:89-114) per (track, joint); tracks that
+    //           see many views split each joint's row folding over 4 lanes and merge the triangular factors ------------
+    const int nsplit = maxV > 8 ? 4 : 1;
+    for (int it = tid; it < nT * J * nsplit; it += NT) {
+        const int ij = it / nsplit, q = it % nsplit, i = ij / J, j = ij % J;
         const int V = ws.sel_n[i];
         if (V == 0) continue;
         const int s = st.order[i];
-        const uint32_t km = greedy_keep_update(V, ws.conf + ((size_t)i * J + j) * C, ws.rayd + ((size_t)i * J + j) * C);
-        const int nv = __popc(km);
-        ws.keep[i * J + j] = km; ws.nview[i * J + j] = nv;
-        double X[3];
-        if (nv >= 2) {
-            const int* scid = ws.sel_cid + i * C;
-            dlt_joint(cs, V, scid, ws.sel_T + i * C, prm.w_lambda_t, prm.lambda_t, km,
-                      [&](int v) { return st.p2d_pose + ((size_t)s * C + scid[v]) * J3 + j * 3; }, X);
-        } else {
-            X[0] = ws.pred[i * J3 + j * 3]; X[1] = ws.pred[i * J3 + j * 3 + 1]; X[2] = ws.pred[i * J3 + j * 3 + 2];
+        uint32_t km;
+        if (nsplit == 1 || q == 0) {
+            km = greedy_keep_update(V, ws.conf + ((size_t)i * J + j) * C, ws.rayd + ((size_t)i * J + j) * C);
+            ws.keep[i * J + j] = km; ws.nview[i * J + j] = __popc(km);
         }
-        ws.raw3d[i * J3 + j * 3] = X[0]; ws.raw3d[i * J3 + j * 3 + 1] = X[1]; ws.raw3d[i * J3 + j * 3 + 2] = X[2];
+        if (nsplit == 1) {
+            double X[3];
+            if (__popc(km) >= 2) {
+                const int* scid = ws.sel_cid + i * C;
+                dlt_joint(cs, V, scid, ws.sel_T + i * C, prm.w_lambda_t, prm.lambda_t, km,
+                          [&](int v) { return st.p2d_pose + ((size_t)s * C + scid[v]) * J3 + j * 3; }, X);
+            } else {
+                X[0] = ws.pred[i * J3 + j * 3]; X[1] = ws.pred[i * J3 + j * 3 + 1]; X[2] = ws.pred[i * J3 + j * 3 + 2];
+            }
+            ws.raw3d[i * J3 + j * 3] = X[0]; ws.raw3d[i * J3 + j * 3 + 1] = X[1]; ws.raw3d[i * J3 + j * 3 + 2] = X[2];
+        }
+    }
+    if (nsplit > 1) {
+        __syncthreads();
+        for (int it = tid; it < nT * J * nsplit; it += NT) {
+            const int ij = it / nsplit, q = it % nsplit, i = ij / J, j = ij % J;
+            const int V = ws.sel_n[i];
+            if (V == 0) continue;
+            const int s = st.order[i];
+            const int* scid = ws.sel_cid + i * C;
+            double R[4][4];
+            dlt_zero(R);
+            dlt_fold(cs, V, q, nsplit, scid, ws.sel_T + i * C, prm.w_lambda_t, prm.lambda_t, ws.keep[i * J + j],
+                     [&](int v) { return st.p2d_pose + ((size_t)s * C + scid[v]) * J3 + j * 3; }, R);
+            dlt_pack(R, ws.rpart + ((size_t)ij * 4 + q) * 10);
+        }
+        __syncthreads();
+        for (int it = tid; it < nT * J; it += NT) {
+            const int i = it / J, j = it % J;
+            if (ws.sel_n[i] == 0) continue;
+            double X[3];
+            if (ws.nview[i * J + j] >= 2) {
+                double R[4][4];
+                dlt_zero(R);
+                for (int q = 0; q < 4; ++q) dlt_merge(R, ws.rpart + ((size_t)it * 4 + q) * 10);
+                dlt_solve(R, X);
+            } else {
+                X[0] = ws.pred[i * J3 + j * 3]; X[1] = ws.pred[i * J3 + j * 3 + 1]; X[2] = ws.pred[i * J3 + j * 3 + 2];
+            }
+            ws.raw3d[i * J3 + j * 3] = X[0]; ws.raw3d[i * J3 + j * 3 + 1] = X[1]; ws.raw3d[i * J3 + j * 3 + 2] = X[2];
+        }
     }
     __syncthreads();
 
+    if (tid == 0) out_d[6] = now_s();
     // ---- P4d: success test (:369) ------------------------------------------------------------------------------
     for (int i = tid; i < nT; i += NT) {
         int okv = 0;
@@ -294,6 +386,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame(FrameArgs A) {
     }
     __syncthreads();
 
+    if (tid == 0) out_d[7] = now_s();
     // ---- P4e: temporal smoothing into the next ring entry (:371-383) -------------------------------------------
     for (int it = tid; it < nT * J3; it += NT) {
         const int i = it / J3, e = it % J3;
@@ -308,6 +401,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame(FrameArgs A) {
         st.hist[((size_t)s * HCAP + (head + len) % HCAP) * J3 + e] = val;
     }
     __syncthreads();
+    if (tid == 0) out_d[8] = now_s();
     // ---- P4f: append + prune history (:330-332) ---------------------------------------------------------------
     for (int i = tid; i < nT; i += NT) {
         if (!ws.ok[i]) continue;
@@ -321,6 +415,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame(FrameArgs A) {
         st.h_head[s] = head; st.h_len[s] = len;
     }
     __syncthreads();
+    if (tid == 0) out_d[9] = now_s();
     // ---- P4g: float32 velocity (:385-395) and life cycle (:253-274) -------------------------------------------
     for (int it = tid; it < nT * J3; it += NT) {
         const int i = it / J3, e = it % J3;
@@ -488,6 +583,7 @@ __global__ __launch_bounds__(BLOCK) void k_frame(FrameArgs A) {
     }
     if (tid == 0) out_d[3] = now_s();
 
+    if (tid == 0) out_d[10] = now_s();
     // ---- P6: drop deleted tracks, keep list order (:178) ------------------------------------------------------
     if (tid == 0) {
         const int n = st.hdr[0];
@@ -525,6 +621,12 @@ __global__ __launch_bounds__(BLOCK) void k_frame(FrameArgs A) {
         double* o = out_d + ol.dbl_hdr_words + (size_t)i * ol.dbl_trk_words;
         o[e] = st.hist[((size_t)s * HCAP + newest) * J3 + e];
         o[J3 + e] = (double)st.vel[s * J3 + e];
+    }
+    if (tid == 0) out_d[11] = now_s();
+    if (A.hot_in_lds) {                                                 // integer scene state back to HBM
+        __syncthreads();
+        const char* st_lds = hot_lds + hot_bytes(d);
+        for (size_t o = (size_t)threadIdx.x * 4; o < st_ints; o += (size_t)blockDim.x * 4) *(int*)(st_glob + o) = *(const int*)(st_lds + o);
     }
 #undef DET
 }
@@ -694,7 +796,7 @@ extern "C" int pam_create(PamHandle** out, int device, int n_views, int max_dets
     ol.off_order = 10; ol.off_matched = 10 + d.C; ol.off_time2d = 10 + 2 * d.C; ol.off_nviews = 10 + 3 * d.C;
     ol.trk_words = 10 + 3 * d.C + J;
     ol.int_words = ol.hdr_words + d.MAXT * ol.trk_words;
-    ol.dbl_hdr_words = 4; ol.dbl_trk_words = 2 * J3;
+    ol.dbl_hdr_words = 16; ol.dbl_trk_words = 2 * J3;
     ol.dbl_words = ol.dbl_hdr_words + d.MAXT * ol.dbl_trk_words;
     h->op_bytes = 8u << 20;
 #define CR(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_err = std::string(#call) + ": " + hipGetErrorString(e_); \
@@ -766,7 +868,12 @@ static int launch_frame(PamHandle* h, hipStream_t s, int frame_id, const int* d_
     A.d = h->d; A.cs = camset(h); A.prm = h->d_prm;
     A.state = h->d_state; A.state_stride = h->state_stride; A.ws = h->d_ws; A.ws_stride = h->ws_stride;
     A.n_det = d_ndet; A.det = d_det; A.out_i = h->d_out_i; A.out_d = h->d_out_d; A.ol = h->ol; A.frame_id = frame_id;
-    hipLaunchKernelGGL(k_frame, dim3(h->d.S), dim3(BLOCK), 0, s, A);
+    const size_t hot = hot_bytes(h->d) + ((state_int_bytes(h->d) + 15) & ~(size_t)15);
+    A.hot_in_lds = hot <= 128 * 1024 ? 1 : 0;
+    // one workgroup per scene; many-camera rigs have ~10^4-10^5 independent (track, view pair, joint) items per frame, so
+    // they get the largest workgroup (16 waves hide the L2 latency of the pose / fundamental-matrix reads)
+    const int block = h->d.C > 8 ? 1024 : BLOCK;
+    hipLaunchKernelGGL(k_frame, dim3(h->d.S), dim3(block), A.hot_in_lds ? hot : 0, s, A);
     HIPCHK(h, hipGetLastError());
     return PAM_OK;
 }

@@ -42,6 +42,12 @@ class PackedConv(object):
 
 
 class HipHRNet(object):
+    count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
+    tile_cfg = -1
+    multi_stream = False
+    groups = 1
+    max_groups = 1
+
     def __init__(self, folded_model, device):
         self.lib = _lib.load()
         self.device = device
