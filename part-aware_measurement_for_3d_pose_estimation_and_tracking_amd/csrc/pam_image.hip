@@ -76,13 +76,14 @@ __device__ __forceinline__ void write_keypoint(int j, Best b, int hm_h, int hm_w
 // NHWC heat-maps (n, H, W, 17) float32: one workgroup per person.  Pixel tiles of 256 x 17 floats are staged through LDS
 // with coalesced 16-byte loads; each lane then owns one pixel and reads its 17 values at stride 17 words (odd stride:
 // conflict-free), keeping 17 running (max, index) pairs in registers.
-#define TILE_PX 256
-__global__ __launch_bounds__(256) void k_decode_nhwc(int n, const float* __restrict__ hm, int hm_h, int hm_w,
+#define TILE_PX 1024
+#define DEC_T 1024            // 16 waves per person: only n (~20) workgroups exist, so each one is as wide as it can be
+__global__ __launch_bounds__(DEC_T) void k_decode_nhwc(int n, const float* __restrict__ hm, int hm_h, int hm_w,
                                                      const int* __restrict__ view_of, const int* __restrict__ slot_of,
                                                      const float* __restrict__ boxes, int max_dets, double* __restrict__ det,
                                                      float* __restrict__ kp) {
     __shared__ __attribute__((aligned(16))) float tile[TILE_PX * J];
-    __shared__ Best red[4][J];
+    __shared__ Best red[DEC_T / 64][J];
     const int crop = blockIdx.x, tid = threadIdx.x;
     const int HW = hm_h * hm_w;
     const float* src = hm + (size_t)crop * HW * J;
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256) void k_decode_nhwc(int n, const float* __restr
         const float* g = src + (size_t)base * J;
         if ((nfl & 3) == 0 && (((uintptr_t)g & 15) == 0)) {
             const float4* g4 = (const float4*)g; float4* t4 = (float4*)tile;
-            for (int e = tid; e < nfl / 4; e += 256) t4[e] = g4[e];
+            for (int e = tid; e < nfl / 4; e += DEC_T) t4[e] = g4[e];
         } else {
-            for (int e = tid; e < nfl; e += 256) tile[e] = g[e];
+            for (int e = tid; e < nfl; e += DEC_T) tile[e] = g[e];
         }
         __syncthreads();
         if (tid < npx) {
@@ -117,7 +118,9 @@ __global__ __launch_bounds__(256) void k_decode_nhwc(int n, const float* __restr
     }
     __syncthreads();
     if (tid < J) {
-        Best b = better(better(red[0][tid], red[1][tid]), better(red[2][tid], red[3][tid]));
+        Best b = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < DEC_T / 64; ++w) b = better(b, red[w][tid]);
         double* row = det + ((size_t)view_of[crop] * max_dets + slot_of[crop]) * J * 3;
         write_keypoint(tid, b, hm_h, hm_w, boxes + crop * 4, row, kp ? kp + (size_t)crop * J * 3 : nullptr);
     }
@@ -164,7 +167,7 @@ extern "C" int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmap
         hipLaunchKernelGGL(k_decode_nchw, dim3(n * J), dim3(256), 0, (hipStream_t)stream, n, dev_heatmaps, hm_h, hm_w,
                            dev_view_of, dev_slot_of, dev_boxes, max_dets, dev_det, dev_kp_xyc);
     else
-        hipLaunchKernelGGL(k_decode_nhwc, dim3(n), dim3(256), 0, (hipStream_t)stream, n, dev_heatmaps, hm_h, hm_w,
+        hipLaunchKernelGGL(k_decode_nhwc, dim3(n), dim3(DEC_T), 0, (hipStream_t)stream, n, dev_heatmaps, hm_h, hm_w,
                            dev_view_of, dev_slot_of, dev_boxes, max_dets, dev_det, dev_kp_xyc);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

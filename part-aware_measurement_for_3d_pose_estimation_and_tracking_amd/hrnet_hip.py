@@ -5,6 +5,7 @@ The folded (conv + bias) PyTorch module of hrnet.py is walked once into packed w
 ``pam_upsample_add_nhwc_bf16`` per fuse-layer output that has coarser inputs.  Activations are NHWC bf16 torch tensors
 (channels-last); torch is used for memory and the stream only.  The whole forward is hipGraph-capturable."""
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -42,6 +43,9 @@ class PackedConv(object):
 
 
 class HipHRNet(object):
+    # 'barrier': branch streams join/fork through the caller's stream after every stage (hipGraph-capturable);
+    # 'events': pairwise event dependencies (eager only: hipGraph capture of that pattern crashes in ROCm 7.2 at capture end)
+    sync_mode = os.environ.get('PAM_HRNET_SYNC', 'barrier')
     count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
     tile_cfg = -1
     multi_stream = False
@@ -55,9 +59,7 @@ class HipHRNet(object):
         self.tile_cfg = -1
         # concurrency: the 2-4 branches of an HR module run on side streams; the crop batch can additionally be split into
         # `groups` independent sub-batches, each with its own stream set (the kernels are latency-bound, not chip-filling)
-        self.max_groups = 4
-        self.group_streams = [torch.cuda.Stream(device) for _ in range(self.max_groups)]
-        self.side_streams = [[torch.cuda.Stream(device) for _ in range(3)] for _ in range(self.max_groups + 1)]
+        self.side_streams = [[torch.cuda.Stream(device) for _ in range(3)]]
         self.side = self.side_streams[0]
         self.multi_stream = True
         self.groups = 1
@@ -100,6 +102,8 @@ class HipHRNet(object):
         ho = (h + 2 * op.pad - op.kh) // op.stride + 1
         wo = (w + 2 * op.pad - op.kw) // op.stride + 1
         y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        if getattr(self, '_keep', None) is not None:
+            self._keep.append(y)
         if self.count is not None:       # unique bytes this conv must move: input + weights + bias [+ residual] + output
             self.count['bytes'] += 2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin + (y.numel() if res is not None else 0)) + 4 * op.cout
             self.count['flops'] += 2 * y.numel() * op.kh * op.kw * op.cin
@@ -119,6 +123,8 @@ class HipHRNet(object):
     def upsample_add(self, base, terms, shifts, relu):
         n, c, h, w = base.shape
         y = torch.empty_like(base)
+        if getattr(self, '_keep', None) is not None:
+            self._keep.append(y)
         if self.count is not None:
             self.count['bytes'] += 2 * (2 * base.numel() + sum(t.numel() for t in terms))
             self.count['launches'] += 1
@@ -134,78 +140,116 @@ class HipHRNet(object):
         return y
 
     # -- network ------------------------------------------------------------------------------------------------------
-    def _hr_module(self, mod, xs):
-        xs = list(xs)
-        ms = self.multi_stream and len(mod['branches']) > 1
-        cur = torch.cuda.current_stream(self.device) if ms else None
-        for b, blocks in enumerate(mod['branches']):
-            st = self.side[b - 1] if (ms and b > 0) else None
-            if st is not None:
+    # Stream plan: branch b of every HR module, and fuse output b, always run on stream b (stream 0 = the caller's stream);
+    # cross-branch inputs are ordered by events, not by global joins, so a branch starts its next module as soon as ITS fuse
+    # output exists.  Every tensor of a forward is kept alive until the forward has been issued (self._keep), so the caching
+    # allocator can never hand a block that another stream still reads to a new tensor; all streams join at the end.
+    def _stream(self, b):
+        return None if (b == 0 or not self.multi_stream) else self.side[b - 1]
+
+    def _barrier(self):
+        """Join and re-fork all branch streams through the caller's stream."""
+        if self.multi_stream:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.side:
+                cur.wait_stream(st)
+            for st in self.side:
                 st.wait_stream(cur)
-            with torch.cuda.stream(st):
+
+    def _record(self, b):
+        if not self.multi_stream or self.sync_mode == 'barrier':
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device) if b == 0 else self.side[b - 1])
+        return ev
+
+    def _wait(self, b, ev):
+        if ev is not None:
+            (torch.cuda.current_stream(self.device) if b == 0 else self.side[b - 1]).wait_event(ev)
+
+    def _hr_module(self, mod, xs, ready):
+        """xs[b]: tensor or ('lazy', op, src_tensor, src_event) for a branch created by a transition; ready[b]: event."""
+        nb = len(mod['branches'])
+        xs, ready = list(xs), list(ready)
+        for b, blocks in enumerate(mod['branches']):
+            with torch.cuda.stream(self._stream(b)):
                 x = xs[b]
+                if isinstance(x, tuple):                              # transition conv runs on the new branch's own stream
+                    _, op, src, ev = x
+                    self._wait(b, ev)
+                    x = self.conv(op, src, relu=True)
                 for c1, c2 in blocks:
                     y = self.conv(c1, x, relu=True)
                     x = self.conv(c2, y, res=x, relu=True)
                 xs[b] = x
-        if ms:
-            for b in range(1, len(mod['branches'])):
-                cur.wait_stream(self.side[b - 1])
-        out = []
+                ready[b] = self._record(b)
+        if self.sync_mode == 'barrier':
+            self._barrier()
+        # fuse: out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)); all terms of output i on
+        # stream i, ONE k_upsample_add per output (shift 0 for the same-resolution down terms)
+        out, oready = [None] * len(mod['fuse']), [None] * len(mod['fuse'])
         for i, row in enumerate(mod['fuse']):
-            ups = [(f[1], f[2], j) for j, f in enumerate(row) if f is not None and f[0] == 'up']
-            downs = [(f[1], j) for j, f in enumerate(row) if f is not None and f[0] == 'down']
-            acc = xs[i]
-            if ups:
-                terms = [self.conv(op, xs[j]) for op, _, j in ups]
-                acc = self.upsample_add(acc, terms, [s for _, s, _ in ups], relu=not downs)
-            for q, (chain, j) in enumerate(downs):
-                t = xs[j]
-                for k, op in enumerate(chain):
-                    if k < len(chain) - 1:
-                        t = self.conv(op, t, relu=True)
+            with torch.cuda.stream(self._stream(i)):
+                terms, shifts = [], []
+                for j, f in enumerate(row):
+                    if f is None:
+                        continue
+                    self._wait(i, ready[j])
+                    if f[0] == 'up':
+                        terms.append(self.conv(f[1], xs[j])); shifts.append(f[2])
                     else:
-                        acc = self.conv(op, t, res=acc, relu=(q == len(downs) - 1))
-            if not ups and not downs:
-                acc = torch.relu(acc)
-            out.append(acc)
-        return out
+                        t = xs[j]
+                        for k, op in enumerate(f[1]):
+                            t = self.conv(op, t, relu=(k < len(f[1]) - 1))
+                        terms.append(t); shifts.append(0)
+                out[i] = self.upsample_add(xs[i], terms, shifts, relu=True) if terms else torch.relu(xs[i])
+                oready[i] = self._record(i)
+        if self.sync_mode == 'barrier':
+            self._barrier()
+        return out, oready
 
     def features(self, x8):
         """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
-        g = min(self.groups, self.max_groups, x8.shape[0])
-        if g <= 1:
-            self.side = self.side_streams[0]
-            return self._features(x8)
-        cur = torch.cuda.current_stream(self.device)
-        parts = x8.chunk(g)
-        outs = []
-        for k, xp in enumerate(parts):
-            st = self.group_streams[k]
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                self.side = self.side_streams[k + 1]
-                outs.append(self._features(xp))
-        for k in range(len(parts)):
-            cur.wait_stream(self.group_streams[k])
-        self.side = self.side_streams[0]
-        return torch.cat(outs, dim=0)
+        self._keep = []
+        self.side = self.side_streams[0] if hasattr(self, 'side_streams') else None
+        return self._features(x8)
 
     def _features(self, x8):
+        ms = self.multi_stream
+        cur = torch.cuda.current_stream(self.device) if ms else None
+        if ms:
+            for st in self.side:
+                st.wait_stream(cur)
         x = self.conv(self.conv1, x8, relu=True)
         x = self.conv(self.conv2, x, relu=True)
         for b in self.layer1:
-            r = x if b['down'] is None else self.conv(b['down'], x)
+            if b['down'] is not None and ms and self.sync_mode == 'events':   # 1x1 skip projection beside the main path
+                ev0 = self._record(0)
+                with torch.cuda.stream(self._stream(1)):
+                    self._wait(1, ev0)
+                    r = self.conv(b['down'], x)
+                    evr = self._record(1)
+            else:
+                r = x if b['down'] is None else self.conv(b['down'], x)
+                evr = None
             y = self.conv(b['c1'], x, relu=True)
             y = self.conv(b['c2'], y, relu=True)
+            self._wait(0, evr)
             x = self.conv(b['c3'], y, res=r, relu=True)
-        xs = [self.conv(self.t1[0], x, relu=True), self.conv(self.t1[1], x, relu=True)]
+        ev = self._record(0)
+        if self.sync_mode == 'barrier':
+            self._barrier()                                           # branch streams must see layer1's output
+        xs = [('lazy', self.t1[0], x, ev), ('lazy', self.t1[1], x, ev)]
+        ready = [ev, ev]
         for m in self.stage2:
-            xs = self._hr_module(m, xs)
-        xs = xs + [self.conv(self.t2, xs[-1], relu=True)]
+            xs, ready = self._hr_module(m, xs, ready)
+        xs = xs + [('lazy', self.t2, xs[-1], ready[-1])]; ready = ready + [ready[-1]]
         for m in self.stage3:
-            xs = self._hr_module(m, xs)
-        xs = xs + [self.conv(self.t3, xs[-1], relu=True)]
+            xs, ready = self._hr_module(m, xs, ready)
+        xs = xs + [('lazy', self.t3, xs[-1], ready[-1])]; ready = ready + [ready[-1]]
         for m in self.stage4:
-            xs = self._hr_module(m, xs)
+            xs, ready = self._hr_module(m, xs, ready)
+        if ms:
+            for st in self.side:
+                cur.wait_stream(st)
         return xs[0]
