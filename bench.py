@@ -169,8 +169,8 @@ def main():
             'value': fps, 'unit': 'frames/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'bf16 convs / f64 matching', 'data': 'synthetic',
-            'config': {'workload': 'Shelf-like %s: %d cams %dx%d, %d persons, %d crops/frame 384x288, 17 joints'
-                                   % (size, C, fw, fh, P, int(np.median(crops_per_frame))),
+            'config': {'workload': '%s-like %s: %d cams %dx%d, %d persons, %d crops/frame 384x288, 17 joints'
+                                   % ({'S1': 'Campus', 'S2': 'Shelf', 'S3': 'Panoptic-5', 'S4': 'Panoptic-31'}[size], size, C, fw, fh, P, int(np.median(crops_per_frame))),
                        'views_per_rank': [len(p) for p in pipe.gather.parts], 'tracker': 'fused HIP frame kernel (f64)',
                        'hrnet_weights': pipe.net.weights if pipe.net else None, 'conv_backend': pipe.net.backend if pipe.net else None, 'exchange': 'all_gather per frame' if world > 1 else 'none'},
             'roofline': {'kernel': 'HRNet-W48 conv stack: k_conv3x3 / k_conv_igemm / k_upsample_add (hipGraph replay, %d crops, %d launches)'

@@ -229,20 +229,25 @@ struct C3Args {
     const uint16_t* in; const uint16_t* wimg; const float* bias; const uint16_t* res; uint16_t* out;
     int N, H, W, Cout, TH, tiles_y, relu, dbg;
     float inv_pw;
+    unsigned long long* stamps;      // diagnostic build only (dbg & 64): per-workgroup s_memtime stamps, never read by the kernel
 };
-__host__ __device__ constexpr int c3_ck(int cin) { return cin == 48 ? 48 : 32; }
-__host__ __device__ constexpr int c3_pitch_a(int) { return 96; }                         // 32 (mod 64): see tools/lds_sim.py
-__host__ __device__ constexpr int c3_pitch_w(int cin) { return cin == 48 ? 864 : 608; }
-__host__ __device__ constexpr int c3_maxpatch(int mt, int nwaves) { return 16 * mt * nwaves + 160; }
+static unsigned long long* g_c3_stamps = nullptr;
+extern "C" int pam_conv_debug_stamps(void* dev_buf) { g_c3_stamps = (unsigned long long*)dev_buf; return PAM_OK; }
+// chunk of input channels resident in LDS per K pass: all 48 for Cin = 48 (K walked as the flattened (tap, c) index), 64 for the
+// deep small-image layers (fewer, longer passes hide the load latency), 32 otherwise.  Pitches from tools/lds_sim.py:
+// conflict-free ds_read_b128 needs pitch = 32 (mod 64) bytes for the pixel rows and these row pitches for the weights.
+__host__ __device__ constexpr int c3_ck(int cin) { return cin == 48 ? 48 : (cin >= 192 ? 64 : 32); }
+__host__ __device__ constexpr int c3_pitch_a(int cin) { return c3_ck(cin) == 64 ? 160 : 96; }
+__host__ __device__ constexpr int c3_pitch_w(int cin) { return cin == 48 ? 864 : (c3_ck(cin) == 64 ? 1184 : 608); }
 
 __device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }   // exact for x < 2^16
 
-template <int CIN, int NTW, int MT, int NWAVES>
+template <int CIN, int NTW, int MT, int NWAVES, int PMAX>
 __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     constexpr int T = 64 * NWAVES, BN = 16 * NTW;
     constexpr int CK = c3_ck(CIN), NCHUNK = CIN / CK, PC8 = CK / 8;
     constexpr int PITCH_A = c3_pitch_a(CIN), PITCH_W = c3_pitch_w(CIN);
-    constexpr int NPP = (c3_maxpatch(MT, NWAVES) * PC8 + T - 1) / T;     // patch pieces per thread per chunk
+    constexpr int NPP = (PMAX * PC8 + T - 1) / T;                        // patch pieces per thread per chunk (PMAX >= patch pixels)
     constexpr int WIMG = BN * PITCH_W;                                    // bytes of one weight chunk image
     constexpr int NWP = (WIMG / 16 + T - 1) / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     const int th = min(a.TH, a.H - ty0);                // ragged last tile
     const int PW = a.W + 2, npatch = (th + 2) * PW, nslots = th * PW;
     const int n0 = blockIdx.y * BN;
-    char* Wsm = smem + (size_t)(c3_maxpatch(MT, NWAVES)) * PITCH_A;       // fixed offset: patch region has room for junk-column reads
+    char* Wsm = smem + ((((size_t)npatch + 2) * PITCH_A + 15) & ~(size_t)15);   // junk-slot reads past the patch land in the weights (in bounds)
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * CIN * 2), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, (int)((size_t)(a.Cout / BN) * NCHUNK * WIMG), 0x00020000);
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
@@ -271,6 +276,8 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
             rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, q < WIMG / 16 ? (unsigned)(q * 16) : OOB_OFFSET, wimg0 + (unsigned)cc * WIMG, 0);
         }
     };
+#define C3_STAMP(k) do { if ((a.dbg & 64) && tid == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    C3_STAMP(0);
     if (!(a.dbg & 1)) gload_w(0);                       // in flight while the patch descriptors are computed
 
     // ---- per-thread patch piece descriptors (fixed over the chunk loop) -------------------------------------------------
@@ -319,10 +326,14 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
 
     if (a.dbg & 16) { if (goffA[0] == 12345u) a.out[0] = 1; return; }
     if (!(a.dbg & 1)) gload_a(0);
+    C3_STAMP(1);
     for (int cc = 0; cc < NCHUNK; ++cc) {
         if (cc > 0) __syncthreads();                    // every wave is done reading the previous chunk
+        C3_STAMP(2 + 4 * cc);
         if (!(a.dbg & 32)) lstore();
+        C3_STAMP(3 + 4 * cc);
         __syncthreads();
+        C3_STAMP(4 + 4 * cc);
         if (cc + 1 < NCHUNK && !(a.dbg & 1)) gload(cc + 1);             // next chunk in flight under the MFMAs below
         if (cc == NCHUNK - 1 && a.res) {                                // residual tile in flight under the last chunk's MFMAs
 #pragma unroll
@@ -336,51 +347,50 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
             }
         }
         if (a.dbg & 2) continue;
-        if constexpr (CIN == 48) {
-#pragma unroll
-            for (int s = 0; s < 14; ++s) {
-                const int k0 = 32 * s + 8 * g;                           // flattened (tap, c); an 8-slice never straddles taps
+        // K loop, software-pipelined by hand: the fragments of step s+1 are read from LDS while the MFMAs of step s issue
+        // (with one wave per SIMD nothing else hides the ds_read latency)
+        constexpr int NSTEP = (CIN == 48) ? 14 : 9 * (CK / 32);
+        bf16x8 af[2][MT], bfr[2][NTW];
+        auto ldfrag = [&](int st, bf16x8* af_, bf16x8* bf_) {
+            if constexpr (CIN == 48) {
+                const int k0 = 32 * st + 8 * g;                          // flattened (tap, c); an 8-slice never straddles taps
                 const int t = k0 / 48, c = k0 - t * 48;
                 const int ky = t / 3, kx = t - ky * 3;
                 const bool zero = k0 >= 432;
                 const unsigned aoff = (unsigned)((ky * PW + kx) * PITCH_A + c * 2);
-                bf16x8 bfr[NTW];
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) bfr[j] = *(const bf16x8*)(wl + (size_t)j * 16 * PITCH_W + k0 * 2);
-                bf16x8 af[MT];
+                for (int j = 0; j < NTW; ++j) bf_[j] = *(const bf16x8*)(wl + (size_t)j * 16 * PITCH_W + k0 * 2);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(zero ? zero_slot : al + (size_t)i * 16 * PITCH_A + aoff);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[j]),
-                                                                           __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
+                for (int i = 0; i < MT; ++i) af_[i] = *(const bf16x8*)(zero ? zero_slot : al + (size_t)i * 16 * PITCH_A + aoff);
+            } else {
+                constexpr int KS = CK / 32;
+                const int t = st / KS, ks = st - t * KS;
                 const int ky = t / 3, kx = t - ky * 3;
-                const unsigned aoff = (unsigned)((ky * PW + kx) * PITCH_A + g * 16);
-                bf16x8 bfr[NTW];
+                const unsigned aoff = (unsigned)((ky * PW + kx) * PITCH_A + ks * 64 + g * 16);
 #pragma unroll
-                for (int j = 0; j < NTW; ++j) bfr[j] = *(const bf16x8*)(wl + (size_t)j * 16 * PITCH_W + t * 64 + g * 16);
-                bf16x8 af[MT];
+                for (int j = 0; j < NTW; ++j) bf_[j] = *(const bf16x8*)(wl + (size_t)j * 16 * PITCH_W + st * 64 + g * 16);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8*)(al + (size_t)i * 16 * PITCH_A + aoff);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NTW; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[j]),
-                                                                           __builtin_bit_cast(bf16x8_t, af[i]), acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MT; ++i) af_[i] = *(const bf16x8*)(al + (size_t)i * 16 * PITCH_A + aoff);
             }
+        };
+        ldfrag(0, af[0], bfr[0]);
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            if (st + 1 < NSTEP) ldfrag(st + 1, af[(st + 1) & 1], bfr[(st + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & 1][j]),
+                                                                       __builtin_bit_cast(bf16x8_t, af[st & 1][i]), acc[i][j], 0, 0, 0);
         }
+        C3_STAMP(5 + 4 * cc);
     }
 
     // ---- epilogue straight from the accumulators.  With the weights as the MFMA A operand the D tile has channels on
     // its rows: this lane holds channels n0 + j*16 + g*4 .. +3 of pixel slot i*16 + (lane & 15) -> one 8-byte residual load
     // and one 8-byte store per (i, j); the 4 lane groups of a pixel cover 32 contiguous bytes.
+    C3_STAMP(60);
     if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)acc[0][0][0]; return; }
     typedef __attribute__((ext_vector_type(4))) short bf16x4;
     f32x4 bias4[NTW];
@@ -406,28 +416,30 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
             }
         }
     }
+    C3_STAMP(61);
 }
 
-template <int CIN, int NTW, int MT, int NWAVES>
-static size_t c3_lds_bytes() {
-    return (size_t)c3_maxpatch(MT, NWAVES) * c3_pitch_a(CIN) + (size_t)16 * NTW * c3_pitch_w(CIN) + 64;
+static size_t c3_lds_bytes(int cin, int ntw, int npatch) {
+    return ((((size_t)npatch + 2) * c3_pitch_a(cin) + 15) & ~(size_t)15) + (size_t)16 * ntw * c3_pitch_w(cin) + 64;
 }
-template <int CIN, int NTW, int MT, int NWAVES>
+template <int CIN, int NTW, int MT, int NWAVES, int PMAX>
 static int launch_c3_one(hipStream_t s, const C3Args& a) {
+    const int npatch = (a.TH + 2) * (a.W + 2);
+    if (npatch > PMAX) return PAM_E_ARG;
     dim3 grid(a.tiles_y * a.N, a.Cout / (16 * NTW));
-    const size_t lds = c3_lds_bytes<CIN, NTW, MT, NWAVES>();
-    hipLaunchKernelGGL((k_conv3x3<CIN, NTW, MT, NWAVES>), grid, dim3(64 * NWAVES), lds, s, a);
+    const size_t lds = c3_lds_bytes(CIN, NTW, npatch);
+    if (lds > 150 * 1024) return PAM_E_ARG;
+    hipLaunchKernelGGL((k_conv3x3<CIN, NTW, MT, NWAVES, PMAX>), grid, dim3(64 * NWAVES), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
-// cfg = MT * 10 + NWAVES  (MT in {4, 8}; NWAVES in {2, 3, 4})
+// cfg = MT * 10 + NWAVES  (MT = 4; NWAVES in {2, 3, 4}); the patch bound PMAX is picked from the actual tile
 template <int CIN, int NTW>
 static int launch_c3(hipStream_t s, const C3Args& a, int cfg) {
+    const int npatch = (a.TH + 2) * (a.W + 2);
     switch (cfg) {
-        case 42: return launch_c3_one<CIN, NTW, 4, 2>(s, a);
-        case 43: return launch_c3_one<CIN, NTW, 4, 3>(s, a);
-        case 44: return launch_c3_one<CIN, NTW, 4, 4>(s, a);
-        case 82: return launch_c3_one<CIN, NTW, 8, 2>(s, a);
-        case 83: return launch_c3_one<CIN, NTW, 8, 3>(s, a);
+        case 42: return npatch <= 160 ? launch_c3_one<CIN, NTW, 4, 2, 160>(s, a) : launch_c3_one<CIN, NTW, 4, 2, 288>(s, a);
+        case 43: return npatch <= 160 ? launch_c3_one<CIN, NTW, 4, 3, 160>(s, a) : launch_c3_one<CIN, NTW, 4, 3, 352>(s, a);
+        case 44: return npatch <= 288 ? launch_c3_one<CIN, NTW, 4, 4, 288>(s, a) : launch_c3_one<CIN, NTW, 4, 4, 416>(s, a);
     }
     return PAM_E_ARG;
 }
@@ -468,7 +480,7 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
         c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.relu = relu; c.inv_pw = 1.0f / (float)(W + 2);
         int cfg = 0;
         pick_rows(N, H, W, Cout, ntw, c.TH, cfg);
-        c.dbg = 0;
+        c.dbg = 0; c.stamps = g_c3_stamps;
         if (tile_cfg >= 100) {                           // test / tuning hook: 100 + dbg bits, or 1000 + TH*100 + cfg
             if (tile_cfg >= 1000) { c.TH = (tile_cfg - 1000) / 100; cfg = (tile_cfg - 1000) % 100; }
             else c.dbg = tile_cfg - 100;

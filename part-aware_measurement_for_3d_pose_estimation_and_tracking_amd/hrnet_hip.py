@@ -34,8 +34,8 @@ class PackedConv(object):
         if kh == 3 and kw == 3 and self.stride == 1 and self.pad == 1 and cin in (48, 64, 96, 192, 384):
             # per-chunk LDS images for k_conv3x3: [cout/BN][cin/CK][BN][pitch/2] bf16, row = 9 taps x CK channels (+ pad)
             bn = 48 if cout % 48 == 0 else 64
-            ck = 48 if cin == 48 else 32
-            pitch = (864 if cin == 48 else 608) // 2
+            ck = 48 if cin == 48 else (64 if cin >= 192 else 32)
+            pitch = {48: 864, 32: 608, 64: 1184}[ck] // 2
             w5 = w.permute(0, 2, 3, 1).reshape(cout // bn, bn, 9, cin // ck, ck)        # [slab][co][tap][chunk][c]
             img = torch.zeros((cout // bn, cin // ck, bn, pitch), dtype=torch.float32)
             img[:, :, :, :9 * ck] = w5.permute(0, 3, 1, 2, 4).reshape(cout // bn, cin // ck, bn, 9 * ck)
