@@ -52,11 +52,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hooks (single-GPU boxes): PAM_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, PAM_BENCH_BACKEND=gloo swaps RCCL out
+    if os.environ.get('PAM_BENCH_SINGLE_DEVICE') == '1':
+        local_rank = 0
+    backend = os.environ.get('PAM_BENCH_BACKEND', 'nccl')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda:%d' % local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda:%d' % local_rank))
+        else:
+            dist.init_process_group(backend)
     assert args.gpus == world, '--gpus must equal the number of launched ranks (use torch.distributed.run for N>1)'
     dev = torch.device('cuda:%d' % local_rank)
     torch.cuda.set_device(dev)

@@ -253,7 +253,14 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (a.dbg & 8) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-    const int ty = blockIdx.x % a.tiles_y, n = blockIdx.x / a.tiles_y;
+    // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2), so give each XCD a contiguous run of
+    // tiles -- vertically adjacent tiles re-read each other's halo rows, which then hit that L2 instead of the fabric
+    int bx;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int ty = bx % a.tiles_y, n = bx / a.tiles_y;
     const int ty0 = ty * a.TH;
     const int th = min(a.TH, a.H - ty0);                // ragged last tile
     const int PW = a.W + 2, npatch = (th + 2) * PW, nslots = th * PW;
