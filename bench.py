@@ -207,7 +207,7 @@ def main():
         if n > 0 and pipe.net is not None:
             x = pipe.net.input_buffer(n)
             s = ev_time(lambda: pipe.net.preprocess(frame_ptrs, fh, fw, vl, bx, x))
-            by = float((bx[:, 2] * bx[:, 3]).sum().item()) * 3 + n * 3 * 384 * 288 * 2
+            by = float((bx[:, 2] * bx[:, 3]).sum().item()) * 3 + n * x.shape[1] * 384 * 288 * 2
             kern.append({'kernel': 'k_preprocess_crops', 'bound': 'hbm', 'achieved': by / s / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': by / s / 1e9 / HBM_PEAK_GBS, 'us': s * 1e6, 'bytes': by})
             hm = pipe.net.heatmaps(x)
