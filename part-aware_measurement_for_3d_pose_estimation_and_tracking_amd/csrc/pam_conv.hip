@@ -127,20 +127,27 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
         if (c + 1 < nchunks) load_chunk();             // loads in flight under the MFMAs below
         const char* Ab = As + (size_t)buf * BM * ROWB + (wm * 64 + (lane & 15)) * ROWB + (lane >> 4) * 16;
         const char* Bb = Bs + (size_t)buf * BN * ROWB + (wn * 16 * NTW + (lane & 15)) * ROWB + (lane >> 4) * 16;
+        // both 32-deep steps of the chunk: all fragment reads first, pinned ahead of the MFMAs (hipcc otherwise sinks each
+        // ds_read to just before its first use and the LDS latency is exposed every three MFMAs)
+        bf16x8 af[2][4], bfr[2][NTW];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[NTW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(Ab + i * 16 * ROWB + ks * 64);
+            for (int i = 0; i < 4; ++i) af[ks][i] = *(const bf16x8*)(Ab + i * 16 * ROWB + ks * 64);
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) bfr[j] = *(const bf16x8*)(Bb + j * 16 * ROWB + ks * 64);
+            for (int j = 0; j < NTW; ++j) bfr[ks][j] = *(const bf16x8*)(Bb + j * 16 * ROWB + ks * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]),
-                                                                       __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
+                                                                       __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < nchunks) { store_chunk(buf ^ 1); advance(); }
         __syncthreads();
     }
@@ -242,8 +249,10 @@ __host__ __device__ constexpr int c3_pitch_w(int cin) { return cin == 48 ? 864 :
 
 __device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }   // exact for x < 2^16
 
+// the deep small-image layers run one workgroup per CU (one wave per SIMD): give those instantiations the whole register
+// file, otherwise the scheduler, starved by the chunk-prefetch registers, reads each MFMA fragment right before its use
 template <int CIN, int NTW, int MT, int NWAVES, int PMAX>
-__global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
+__global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_conv3x3(C3Args a) {
     constexpr int T = 64 * NWAVES, BN = 16 * NTW;
     constexpr int CK = c3_ck(CIN), NCHUNK = CIN / CK, PC8 = CK / 8;
     constexpr int PITCH_A = c3_pitch_a(CIN), PITCH_W = c3_pitch_w(CIN);
@@ -384,12 +393,14 @@ __global__ __launch_bounds__(64 * NWAVES) void k_conv3x3(C3Args a) {
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) {
             if (st + 1 < NSTEP) ldfrag(st + 1, af[(st + 1) & 1], bfr[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);          // keep the next step's ds_reads ahead of this step's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[st & 1][j]),
                                                                        __builtin_bit_cast(bf16x8_t, af[st & 1][i]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         C3_STAMP(5 + 4 * cc);
     }
