@@ -159,12 +159,14 @@ int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw
  * implicit GEMM on v_mfma_f32_16x16x32_bf16 with fused epilogue out = [relu](conv + bias [+ residual]).  w_packed is
  * [Cout][Kpad] bf16, k = (ky, kx, cin) flattened, zero-padded to Kpad = roundup(KH*KW*Cin, 64); bias float32 or NULL;
  * residual NHWC bf16 of the output shape or NULL.  tile_cfg < 0 = choose automatically.  w_img (optional, 3x3 stride-1 layers
- * with Cin in {48,64,96,192,384}): the same weights pre-packed as per-chunk LDS images [Cout/BN][Cin/CK][BN][9*CK + pad] (BN = 48
- * or 64; CK = 48 if Cin == 48, 64 if Cin >= 192, else 32; row pitch 864 / 1184 / 608 bytes) for the rows-in-LDS kernel k_conv3x3; NULL = generic kernel.
+ * with Cin in {48,64,96,192,384}): the same weights pre-packed as per-chunk LDS images [Cout/BN][Cin/CK][BN][9*CK + pad] (BN =
+ * pam_conv3x3_slab(H, W, Cin, Cout); CK = 48 if Cin == 48, 64 if Cin >= 192, else 32; row pitch 864 / 1184 / 608 bytes) for the rows-in-LDS kernel k_conv3x3; NULL = generic kernel.
  * pam_upsample_add_nhwc_bf16: the HRNet fuse-layer sum out = [relu](base + sum_t nearest_upsample(term_t, 2^shift_t)). */
 int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                          const void* residual, void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int relu, int tile_cfg);
+/* output channels per workgroup slab (BN) that k_conv3x3 uses for a layer shape; weight images must be packed with it */
+int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
 /* diagnostic builds only: device buffer (64 x uint64 per workgroup) for k_conv3x3's s_memtime stamps, used when tile_cfg = 100 + 64 */
 int pam_conv_debug_stamps(void* dev_buf);
 int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, const void* const* terms,

@@ -63,6 +63,7 @@ _SIGS = {
     'pam_preprocess_crops': (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P]),
     'pam_decode_heatmaps': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     'pam_conv2d_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 11),
+    'pam_conv3x3_slab': (_I, [_I, _I, _I, _I]),
     'pam_conv_debug_stamps': (_I, [_P]),
     'pam_upsample_add_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
 }

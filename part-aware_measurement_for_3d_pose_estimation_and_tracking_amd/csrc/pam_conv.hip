@@ -8,6 +8,7 @@
 // k_upsample_add: the HRNet fuse-layer sum  out = [ReLU](base + sum_t nearest_upsample(term_t)).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/pam.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;     // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
@@ -477,6 +478,16 @@ static void pick_rows(int N, int H, int W, int Cout, int ntw, int& TH, int& cfg)
     for (int t = TH; t >= 1 && t * 100 >= TH * 85; --t) if (H % t == 0) { TH = t; break; }
 }
 
+// output channels per workgroup slab of k_conv3x3 (the host packs the weight images with the same number).  The deep, small
+// images (24x18, 12x9) have too few pixel tiles to fill 256 CUs, so their slabs are narrower: more, shorter workgroups.
+extern "C" int pam_conv3x3_slab(int H, int W, int Cin, int Cout) {
+    const int wide = (Cout % 48 == 0) ? 48 : 64;
+    if (Cin < 192 || Cout % 48 != 0) return wide;
+    const int env = getenv("PAM_C3_SLAB") ? atoi(getenv("PAM_C3_SLAB")) : 0;      // tuning hook
+    if (env == 16 || env == 32 || env == 48) return env;
+    return H * W <= 128 ? 16 : (H * W <= 512 ? 32 : 48);
+}
+
 extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                                     const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
                                     int KH, int KW, int stride, int pad, int relu, int tile_cfg) {
@@ -492,7 +503,7 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
     if (H >= 32768 || W >= 32768) return PAM_E_ARG;
     if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&
         (Cin == 48 || Cin == 64 || Cin == 96 || Cin == 192 || Cin == 384)) {
-        const int ntw = (Cout % 48 == 0) ? 3 : 4;
+        const int ntw = pam_conv3x3_slab(H, W, Cin, Cout) / 16;
         C3Args c;
         c.in = a.in; c.wimg = (const uint16_t*)w_img; c.bias = bias; c.res = a.res; c.out = a.out;
         c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.relu = relu; c.inv_pw = 1.0f / (float)(W + 2);
@@ -506,23 +517,23 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
         if (c.TH * (W + 2) > 16 * (cfg / 10) * (cfg % 10)) return PAM_E_ARG;
         c.tiles_y = (H + c.TH - 1) / c.TH;
         hipStream_t s = (hipStream_t)stream;
-        if (ntw == 3) {
-            switch (Cin) {
-                case 48: return launch_c3<48, 3>(s, c, cfg);
-                case 64: return launch_c3<64, 3>(s, c, cfg);
-                case 96: return launch_c3<96, 3>(s, c, cfg);
-                case 192: return launch_c3<192, 3>(s, c, cfg);
-                case 384: return launch_c3<384, 3>(s, c, cfg);
-            }
-        } else {
-            switch (Cin) {
-                case 48: return launch_c3<48, 4>(s, c, cfg);
-                case 64: return launch_c3<64, 4>(s, c, cfg);
-                case 96: return launch_c3<96, 4>(s, c, cfg);
-                case 192: return launch_c3<192, 4>(s, c, cfg);
-                case 384: return launch_c3<384, 4>(s, c, cfg);
-            }
+        switch (Cin * 10 + ntw) {
+            case 483: return launch_c3<48, 3>(s, c, cfg);
+            case 643: return launch_c3<64, 3>(s, c, cfg);
+            case 963: return launch_c3<96, 3>(s, c, cfg);
+            case 1923: return launch_c3<192, 3>(s, c, cfg);
+            case 3843: return launch_c3<384, 3>(s, c, cfg);
+            case 484: return launch_c3<48, 4>(s, c, cfg);
+            case 644: return launch_c3<64, 4>(s, c, cfg);
+            case 964: return launch_c3<96, 4>(s, c, cfg);
+            case 1924: return launch_c3<192, 4>(s, c, cfg);
+            case 3844: return launch_c3<384, 4>(s, c, cfg);
+            case 1922: return launch_c3<192, 2>(s, c, cfg);
+            case 3842: return launch_c3<384, 2>(s, c, cfg);
+            case 1921: return launch_c3<192, 1>(s, c, cfg);
+            case 3841: return launch_c3<384, 1>(s, c, cfg);
         }
+        return PAM_E_ARG;
     }
     if (tile_cfg >= 100) tile_cfg = -1;
     return (Cout % 48 == 0) ? dispatch_conv<3>((hipStream_t)stream, a, tile_cfg) : dispatch_conv<4>((hipStream_t)stream, a, tile_cfg);

@@ -30,16 +30,28 @@ class PackedConv(object):
         self.bias = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(cout)).to(device).contiguous()
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.stride, self.pad = conv.stride[0], conv.padding[0]
-        self.wimg = None
-        if kh == 3 and kw == 3 and self.stride == 1 and self.pad == 1 and cin in (48, 64, 96, 192, 384):
-            # per-chunk LDS images for k_conv3x3: [cout/BN][cin/CK][BN][pitch/2] bf16, row = 9 taps x CK channels (+ pad)
-            bn = 48 if cout % 48 == 0 else 64
+        # per-chunk LDS images for k_conv3x3, built lazily per slab width (the kernel picks the slab from the layer's H x W)
+        self._w_ohwi = w.permute(0, 2, 3, 1).contiguous() if (kh == 3 and kw == 3 and self.stride == 1 and self.pad == 1 and
+                                                              cin in (48, 64, 96, 192, 384)) else None
+        self._images = {}
+        self._device = device
+
+    def image(self, h, w):
+        """Weight image [cout/BN][cin/CK][BN][pitch/2] bf16 (row = 9 taps x CK channels + pad) for this layer at input h x w."""
+        if self._w_ohwi is None:
+            return None
+        bn = _lib.load().pam_conv3x3_slab(int(h), int(w), self.cin, self.cout)
+        img = self._images.get(bn)
+        if img is None:
+            cin, cout = self.cin, self.cout
             ck = 48 if cin == 48 else (64 if cin >= 192 else 32)
             pitch = {48: 864, 32: 608, 64: 1184}[ck] // 2
-            w5 = w.permute(0, 2, 3, 1).reshape(cout // bn, bn, 9, cin // ck, ck)        # [slab][co][tap][chunk][c]
-            img = torch.zeros((cout // bn, cin // ck, bn, pitch), dtype=torch.float32)
-            img[:, :, :, :9 * ck] = w5.permute(0, 3, 1, 2, 4).reshape(cout // bn, cin // ck, bn, 9 * ck)
-            self.wimg = img.to(torch.bfloat16).to(device).contiguous()
+            w5 = self._w_ohwi.reshape(cout // bn, bn, 9, cin // ck, ck)                  # [slab][co][tap][chunk][c]
+            t = torch.zeros((cout // bn, cin // ck, bn, pitch), dtype=torch.float32)
+            t[:, :, :, :9 * ck] = w5.permute(0, 3, 1, 2, 4).reshape(cout // bn, cin // ck, bn, 9 * ck)
+            img = t.to(torch.bfloat16).to(self._device).contiguous()
+            self._images[bn] = img
+        return img
 
 
 class HipHRNet(object):
@@ -110,9 +122,10 @@ class HipHRNet(object):
             self.count['launches'] += 1
         if x.device.type == 'meta':
             return y
+        wimg = op.image(h, w)
         st = torch.cuda.current_stream(x.device).cuda_stream
         rc = self.lib.pam_conv2d_nhwc_bf16(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
-                                           C.c_void_p(op.wimg.data_ptr()) if op.wimg is not None else None,
+                                           C.c_void_p(wimg.data_ptr()) if wimg is not None else None,
                                            C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
                                            C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad,
                                            1 if relu else 0, self.tile_cfg)
