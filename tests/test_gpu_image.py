@@ -162,3 +162,34 @@ def test_device_pipeline_decode_to_tracker_vs_oracle():
             assert out == ejv
         emitted += len(em)
     assert emitted > 20
+
+
+def test_predict_dump_format_and_facade_end_to_end():
+    """HRNetPose.predict through the reference-shaped facade: person_bbox_list (BGR frames + xywh boxes) -> dump_results with
+    the keys ivclabpose.PersonTrack_Project3DPose reads (ivclabpose.py:233-246), keypoints inside their boxes, and the
+    result accepted by the tracker step."""
+    from pam.ivclabpose import ivclabpose
+    pose_cfg = dict(NAME='HRPose', C=48, NUM_JOINTS=17, CHECKPOINT_FILE='', MODEL_NAME='HRNet', RESOLUTION=[384, 288])
+    mcfg = dict(synth.MATCHER_CFG['CampusSeq1']); conf = mcfg.pop('CONF_THRESHOLD')
+    model = ivclabpose({'NAME': ''}, pose_cfg, dict(mcfg, NAME='Iterative'), conf)
+    seq = synth.make_sequence('S1', n_frames=2, seed=0)
+    model.GetCameraParameters(seq['calib'], 288, 360)
+    rng = np.random.default_rng(0)
+    frames = [rng.integers(0, 256, (288, 360, 3), dtype=np.uint8) for _ in range(3)]
+    boxes = [[[20.0, 30.0, 100.0, 200.0], [150.5, 40.25, 90.0, 180.0]], [], [[200.0, 60.0, 120.0, 210.0]]]
+    pbl = [[dict(image_id=0, category_id=1, score=0.9, bbox=b, data=frames[v], feature=[]) for b in bs] for v, bs in enumerate(boxes)]
+    dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
+    assert [len(v) for v in dump] == [2, 0, 1]
+    for v, items in enumerate(dump):
+        for it, b in zip(items, boxes[v]):
+            assert set(it) >= {'bbox', 'keypoints', 'keypoints_score', 'feature'}
+            k = np.array(it['keypoints']).reshape(17, 3)
+            assert len(it['keypoints_score']) == 17 and np.allclose(k[:, 2], it['keypoints_score'])
+            assert (k[:, 0] >= b[0] - 1e-3).all() and (k[:, 0] <= b[0] + b[2]).all()       # x inside the box
+            assert (k[:, 1] >= b[1] - 1e-3).all() and (k[:, 1] <= b[1] + b[3]).all()       # y inside the box
+    dump2 = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=2)       # chunked batches: same result
+    for a, b in zip(dump, dump2):
+        for ia, ib in zip(a, b):
+            assert ia['keypoints'] == ib['keypoints']
+    out = model.PersonTrack_Project3DPose(0, pbl, dump, 'SVD')
+    assert len(out) == 9 and len(out[5]) == 0          # nothing confirmed on the first frame
