@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(_HERE))
 import pam  # noqa: E402
 from pam.dataset import GetConfig, LoadFilenames  # noqa: E402
-from pam.evaluation import Evaluate3DPose_PCP, Write3DResult  # noqa: E402
+from pam.evaluation import Evaluate3DPose_PCP, EvaluatePanoptic, Write3DResult  # noqa: E402
 from pam.testmodel import test_ivclabpose_PersonTrack_Project3DPose  # noqa: E402
 
 
@@ -27,7 +27,7 @@ def eval_ivclabpose_PersonTrack_Project3DPose(cfg, inputs):
         pipe['DETECT_MODEL'], pipe['POSE_MODEL'], pipe['PERSON_MATCHER'], os.path.basename(dataset.ROOT)))
     Write3DResult(multi_poses3d, path)
     if dataset.TEST_DATASET == 'Panoptic':
-        print('Panoptic AP / MPJPE evaluation is not part of this build (SURVEY 8f rank 3); result written to', path)
+        EvaluatePanoptic(dataset.EVAL_RANGE, path, dataset.TEST_DATASET, seqs=dataset.FOLDERS_ORDER, data_root=dataset.ROOT)
     else:
         Evaluate3DPose_PCP(dataset.EVAL_RANGE, path, gt_path=dataset.ROOT, dataset_name=dataset.TEST_DATASET)
 

@@ -106,3 +106,92 @@ def Write3DResult(multi_poses3d, filepath):
     os.makedirs(os.path.dirname(filepath) or '.', exist_ok=True)
     with open(filepath, 'wb') as f:
         pickle.dump(multi_poses3d, f)
+
+
+# ---- Panoptic AP / recall / MPJPE (evalmodel.py:208-350), restated -------------------------------------------------------
+_PANOPTIC_M = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]])
+_COCO_TO_PANOPTIC13 = [0, 5, 7, 9, 11, 13, 15, 6, 8, 10, 12, 14, 16]
+
+
+def panoptic_gt_from_bodies(bodies_joints19):
+    """(n,19,4) raw joints19 of one annotation file -> (poses (k,14,3) in mm, vis (k,14) bool), bodies whose mid-hip is not
+    visible dropped (evalmodel.py:228-248)."""
+    poses, vis = [], []
+    for j19 in bodies_joints19:
+        p = np.asarray(j19, dtype=np.float64).reshape(-1, 4)[1:15].copy()
+        v = p[:, -1] > 0.1
+        if not v[2]:
+            continue
+        poses.append(p[:, :3].dot(_PANOPTIC_M) * 10.0)
+        vis.append(v)
+    return poses, vis
+
+
+def load_panoptic_gt(data_root, interval=12):
+    """{timestamp: (poses, vis)} from hdPose3d_stage1_coco19/body3DScene_*.json, every `interval`-th file."""
+    import glob
+    import json
+    out = {}
+    files = sorted(glob.glob(os.path.join(data_root, 'hdPose3d_stage1_coco19', '*.json')))
+    for i, fn in enumerate(files):
+        if i % interval:
+            continue
+        with open(fn) as f:
+            bodies = json.load(f)['bodies']
+        if len(bodies) == 0:
+            continue
+        ts = int(os.path.basename(fn)[:-5].replace('body3DScene_', ''))
+        out[ts] = panoptic_gt_from_bodies([b['joints19'] for b in bodies])
+    return out
+
+
+def evaluate_panoptic(gts, preds, thresholds=(25, 50, 75, 100, 125, 150)):
+    """gts {ts: (poses, vis)}, preds {ts: (n,3,17) metres} -> (APs, recalls, MPJPE@500, recall@500)."""
+    ev, total_gt = [], 0
+    for ts, (poses, vis) in gts.items():
+        if len(poses) == 0:
+            continue
+        for pose in preds[ts]:
+            p = np.asarray(pose, dtype=np.float64).T * 1000.0
+            pelvis = (p[11] + p[12]) / 2
+            p14 = np.insert(p[_COCO_TO_PANOPTIC13], 3, pelvis).reshape(-1, 3)
+            errs = [np.mean(np.sqrt(np.sum((p14[v] - g[v]) ** 2, axis=-1))) for g, v in zip(poses, vis)]
+            k = int(np.argmin(errs))
+            ev.append((float(errs[k]), total_gt + k))
+        total_gt += len(poses)
+
+    def ap_at(th):
+        tp, fp, seen = np.zeros(len(ev)), np.zeros(len(ev)), set()
+        for i, (e, gid) in enumerate(ev):
+            if e < th and gid not in seen:
+                tp[i] = 1; seen.add(gid)
+            else:
+                fp[i] = 1
+        tp, fp = np.cumsum(tp), np.cumsum(fp)
+        recall = tp / (total_gt + 1e-5)
+        prec = tp / (tp + fp + 1e-5)
+        for n in range(len(ev) - 2, -1, -1):
+            prec[n] = max(prec[n], prec[n + 1])
+        prec = np.concatenate(([0], prec, [0]))
+        recall = np.concatenate(([0], recall, [1]))
+        idx = np.where(recall[1:] != recall[:-1])[0]
+        return float(np.sum((recall[idx + 1] - recall[idx]) * prec[idx + 1])), float(recall[-2])
+    aps, recs = zip(*[ap_at(t) for t in thresholds])
+    seen, errs = set(), []
+    for e, gid in ev:
+        if e < 500 and gid not in seen:
+            errs.append(e); seen.add(gid)
+    mpjpe = float(np.mean(errs)) if errs else float('inf')
+    rec500 = len({gid for e, gid in ev if e < 500}) / total_gt if total_gt else 0.0
+    return list(aps), list(recs), mpjpe, rec500
+
+
+def EvaluatePanoptic(eval_ranges, pred_path, dataset='Panoptic', seqs=(), data_root='CatchImage/Panoptic/160906_pizza1'):
+    with open(pred_path, 'rb') as f:
+        preds = pickle.load(f)
+    aps, recs, mpjpe, _ = evaluate_panoptic(load_panoptic_gt(data_root), preds)
+    rows = [['Threshold/mm'] + [str(t) for t in (25, 50, 75, 100, 125, 150)], ['AP'] + ['%.2f' % (a * 100) for a in aps],
+            ['Recall'] + ['%.2f' % (r * 100) for r in recs]]
+    print(format_table(rows))
+    print('MPJPE: %.2fmm' % mpjpe)
+    return aps, recs, mpjpe

@@ -35,6 +35,22 @@ def test_pcp_matches_reference():
             assert abs(float(a) - float(b)) < 1e-9, (r, rr)
 
 
+def test_panoptic_eval_matches_reference():
+    z = G.load('panoptic_eval.npz')
+    n = int(z['n_files'])
+    gts, preds = {}, {}
+    for i in range(n):
+        ts = 1000 + i
+        preds[ts] = z['pred.%d' % ts]
+        if i % 12 == 0 and len(z['gt.%d' % ts]):
+            gts[ts] = E.panoptic_gt_from_bodies(z['gt.%d' % ts])
+    aps, recs, mpjpe, _ = E.evaluate_panoptic(gts, preds)
+    assert [round(a * 100, 2) for a in aps] == z['aps'].tolist()
+    assert [round(r * 100, 2) for r in recs] == z['recs'].tolist()
+    assert round(mpjpe, 2) == float(z['mpjpe'])
+    assert 0 < aps[0] < aps[-1] < 1                   # a non-trivial case
+
+
 def test_coco2shelf_layout():
     p = np.arange(51, dtype=float).reshape(3, 17)
     s = E.coco2shelf3D(p)

@@ -355,11 +355,74 @@ def make_pcp(seq, trace, out_path):
                         **{'pred.%d' % t: np.asarray(preds[t], dtype=np.float64).reshape(-1, 3, 17) for t in range(F)})
 
 
+def make_panoptic(out_path):
+    """Synthetic hdPose3d_stage1_coco19/*.json + predictions -> the numbers the reference's EvaluatePanoptic prints
+    (evalmodel.py:208-350; it returns nothing, so stdout is captured)."""
+    import io, json, contextlib
+    sys.path.insert(0, ref_shims.REF)
+    import evalmodel as ref_eval
+    rng = np.random.default_rng(11)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, 'hdPose3d_stage1_coco19'))
+    M = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]])
+    Minv = np.linalg.inv(M)
+    n_files, interval = 60, 12
+    preds, gt_raw = {}, {}
+    for i in range(n_files):
+        ts = 1000 + i
+        nb = int(rng.integers(0, 4)) if i % interval == 0 else 2
+        bodies, pred = [], []
+        for b in range(nb):
+            coco = rng.normal(0, 0.5, (3, 17)) + np.array([[b * 1.5], [0.3], [1.0]])              # metres, (3,17)
+            p = coco.T * 1000.0
+            pelvis = (p[11] + p[12]) / 2
+            p14 = np.insert(p[[0, 5, 7, 9, 11, 13, 15, 6, 8, 10, 12, 14, 16]], 3, pelvis).reshape(-1, 3)
+            noise = rng.normal(0, [5.0, 20.0, 60.0, 120.0][int(rng.integers(4))], p14.shape)       # mm
+            gt14 = p14 + noise
+            raw = np.zeros((19, 4))
+            raw[1:15, :3] = (gt14 / 10.0) @ Minv
+            raw[1:15, 3] = rng.uniform(0.0, 1.0, 14)
+            raw[3, 3] = 0.9 if rng.uniform() > 0.15 else 0.05                                       # joints_vis[2] gate
+            bodies.append({'id': b, 'joints19': raw.reshape(-1).tolist()})
+            if rng.uniform() > 0.1:
+                pred.append(coco)
+        if i % interval == 0 and nb > 0 and rng.uniform() > 0.5:
+            pred.append(rng.normal(0, 0.5, (3, 17)) + np.array([[9.0], [0.3], [1.0]]))             # a false positive
+        with open(os.path.join(tmp, 'hdPose3d_stage1_coco19', 'body3DScene_%08d.json' % ts), 'w') as f:
+            json.dump({'bodies': bodies}, f)
+        preds[ts] = np.array(pred).reshape(-1, 3, 17)
+        gt_raw[ts] = np.array([b['joints19'] for b in bodies]).reshape(-1, 19, 4)
+    pred_path = os.path.join(tmp, 'pred.pkl')
+    with open(pred_path, 'wb') as f:
+        pickle.dump(preds, f)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ref_eval.EvaluatePanoptic([[0, n_files]], pred_path, dataset='Panoptic', seqs=[], data_root=tmp)
+    text = buf.getvalue()
+    lines = [l for l in text.splitlines() if l.strip()]
+    ap_row = [l for l in lines if l.startswith("['AP'")][0]
+    rec_row = [l for l in lines if l.startswith("['Recall'")][0]
+    mp = [l for l in lines if l.startswith('MPJPE')][0]
+    aps = [float(x.strip(" '")) for x in ap_row.strip('[]').split(',')[1:]]
+    recs = [float(x.strip(" '")) for x in rec_row.strip('[]').split(',')[1:]]
+    mpjpe = float(mp.split(':')[1].replace('mm', ''))
+    flat = {'n_files': np.int32(n_files), 'aps': np.array(aps), 'recs': np.array(recs), 'mpjpe': np.float64(mpjpe)}
+    for ts in preds:
+        flat['pred.%d' % ts] = preds[ts]
+        flat['gt.%d' % ts] = gt_raw[ts]
+    np.savez_compressed(out_path, **flat)
+    print('panoptic golden: AP', aps, 'recall', recs, 'MPJPE', mpjpe)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'tests', 'golden'))
+    ap.add_argument('--only-panoptic', action='store_true')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
+    if args.only_panoptic:
+        make_panoptic(os.path.join(args.out, 'panoptic_eval.npz'))
+        return
     install_recorders()
     plans = [
         ('S1', 160, 0, dict(blank_frames=(60,))),
@@ -379,6 +442,7 @@ def main():
               {k: len(v) for k, v in REC.items()})
         if size == 'S2':
             make_pcp(seq, trace, os.path.join(args.out, 'pcp_S2.npz'))
+    make_panoptic(os.path.join(args.out, 'panoptic_eval.npz'))
     print('done ->', args.out)
 
 
