@@ -21,9 +21,13 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {     // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE) on gfx950
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {     // two floats -> one dword of two bf16 (one instruction)
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 constexpr int KC = 64;               // K elements staged per LDS chunk (two 32-deep MFMA steps)
@@ -423,15 +427,16 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
             const size_t o = (((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4;
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                bf16x4 ov;
                 const bf16x4 rr = __builtin_bit_cast(bf16x4, rres[i][j]);
+                float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[i][j][r] + bias4[j][r];
-                    if (a.res) v += bf16_to_f32((uint16_t)rr[r]);
-                    ov[r] = (short)f32_to_bf16_rne(a.relu ? fmaxf(v, 0.0f) : v);
+                    v[r] = acc[i][j][r] + bias4[j][r];
+                    if (a.res) v[r] += bf16_to_f32((uint16_t)rr[r]);
+                    if (a.relu) v[r] = fmaxf(v[r], 0.0f);
                 }
-                *(bf16x4*)(a.out + o + j * 16) = ov;
+                u32x2 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(u32x2*)(a.out + o + j * 16) = ov;
             }
         }
     }

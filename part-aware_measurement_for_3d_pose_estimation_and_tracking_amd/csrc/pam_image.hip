@@ -6,9 +6,8 @@
 
 #define J PAM_J
 
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even; inputs are finite
-    uint32_t u = __float_as_uint(f);
-    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
 
 // One thread per output pixel: bilinear sample (half-pixel centres, border replicate) of the person box from the BGR
