@@ -1,0 +1,88 @@
+"""Frame ingest for the drivers (reference: src/dataset.py:36-45, one cv2.imread per camera per frame on the
+main thread).  With the per-frame compute at a few milliseconds, decoding C JPEGs per frame is the bottleneck of a real run,
+so frames are decoded by a pool of worker threads a few frames ahead (PIL/libjpeg-turbo releases the GIL), written as BGR
+uint8 HxWx3 -- cv2.imread's layout -- into pinned host buffers and, when a device is given, uploaded on a dedicated copy
+stream; the consumer only waits on an event.  Frame order is preserved."""
+import os
+import threading
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def decode_bgr(path, out=None):
+    """One image file -> BGR uint8 (H, W, 3), optionally into a preallocated array."""
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert('RGB'))
+    if out is None:
+        return np.ascontiguousarray(rgb[:, :, ::-1])
+    out[...] = rgb[:, :, ::-1]
+    return out
+
+
+def timestamp_of(dataset_name, first_file):
+    base = os.path.basename(first_file)
+    return int(base.split('_')[-1].split('.')[0]) if dataset_name == 'Panoptic' else base.split('.')[0]
+
+
+class FrameLoader(object):
+    """Iterates (frame_index, imagelist, timestamp) over ``frames`` (list over frames of list over cameras of file names),
+    ``depth`` frames ahead on ``workers`` threads.  imagelist entries are NumPy BGR arrays, or CUDA uint8 tensors when
+    ``device`` is given (pinned staging + async copy on a side stream)."""
+
+    def __init__(self, dataset_name, frames, indices=None, workers=8, depth=4, device=None):
+        self.name, self.frames = dataset_name, frames
+        self.indices = list(range(len(frames))) if indices is None else list(indices)
+        self.depth = max(1, depth)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.device = device
+        self._pinned = {}
+        self._lock = threading.Lock()
+        if device is not None:
+            import torch
+            self.torch = torch
+            self.copy_stream = torch.cuda.Stream(device)
+
+    def _slot_buffers(self, slot, shapes):
+        key = (slot, tuple(shapes))
+        with self._lock:
+            buf = self._pinned.get(key)
+            if buf is None:
+                buf = [self.torch.empty(s, dtype=self.torch.uint8).pin_memory() for s in shapes]
+                self._pinned[key] = buf
+        return buf
+
+    def _submit(self, k):
+        files = self.frames[self.indices[k]]
+        return [self.pool.submit(decode_bgr, f) for f in files]
+
+    def __iter__(self):
+        pending = deque()
+        nxt = 0
+        n = len(self.indices)
+        while nxt < n and len(pending) < self.depth:
+            pending.append((nxt, self._submit(nxt))); nxt += 1
+        while pending:
+            k, futs = pending.popleft()
+            imgs = [f.result() for f in futs]
+            if nxt < n:
+                pending.append((nxt, self._submit(nxt))); nxt += 1
+            ts = timestamp_of(self.name, self.frames[self.indices[k]][0])
+            if self.device is None:
+                yield self.indices[k], imgs, ts
+                continue
+            torch = self.torch
+            stage = self._slot_buffers(k % (self.depth + 1), [im.shape for im in imgs])
+            out = []
+            with torch.cuda.stream(self.copy_stream):
+                for im, pin in zip(imgs, stage):
+                    pin.numpy()[...] = im
+                    out.append(pin.to(self.device, non_blocking=True))
+                ev = torch.cuda.Event(); ev.record(self.copy_stream)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            yield self.indices[k], out, ts
+
+    def close(self):
+        self.pool.shutdown(wait=False)

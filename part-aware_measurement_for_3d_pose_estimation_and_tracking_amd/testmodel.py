@@ -15,7 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(_HERE))
 import pam  # noqa: E402
-from pam.dataset import GetConfig, LoadFilenames, LoadImages  # noqa: E402
+from pam.dataset import GetConfig, LoadFilenames  # noqa: E402
+from pam.ingest import FrameLoader  # noqa: E402
 
 
 def build_model(cfg):
@@ -54,8 +55,8 @@ def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
     t_pose = t_track = 0.0
     start, end = dataset.TEST_RANGE
     n_views = len(dataset.FOLDERS_ORDER)
-    for i, frame_id in enumerate(range(start, end)):
-        imagelist, timestamp = LoadImages(dataset.TEST_DATASET, inputs[frame_id])
+    loader = FrameLoader(dataset.TEST_DATASET, inputs, indices=range(start, end), workers=int(dataset.get('LOADER_THREADS', 8)))
+    for i, (frame_id, imagelist, timestamp) in enumerate(loader):     # decoded a few frames ahead on worker threads
         if i == 0:
             model.GetCameraParameters(camera_parameter, imagelist[0].shape[0], imagelist[0].shape[1])
         pbl, dump, dt_pose = frame_inputs(model, precomputed, frame_id, imagelist)
@@ -70,6 +71,7 @@ def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
         if frame_id > start + 10:
             t_pose += dt_pose
             t_track += dt_track
+    loader.close()
     n = max(1, end - start - 10)
     print("Person Detect Processing time (s/f): %f" % 0.0)
     print("Pose Detect Processing time (s/f): %f" % (t_pose / n))

@@ -88,6 +88,28 @@ def test_natural_sort_and_bgr(tmp_path):
     assert ts == 'img1' and imgs[0].shape == (4, 6, 3) and imgs[0][0, 0, 0] == 12 and imgs[0][0, 0, 2] == 200   # BGR
 
 
+def test_frame_loader_matches_loadimages(tmp_path):
+    from PIL import Image
+    from pam.ingest import FrameLoader
+    rng = np.random.default_rng(0)
+    for cam in ('Camera0', 'Camera1', 'Camera2'):
+        os.makedirs(tmp_path / cam)
+        for i in range(12):
+            Image.fromarray(rng.integers(0, 256, (24, 32, 3), dtype=np.uint8)).save(tmp_path / cam / ('%03d.jpg' % i), quality=90)
+    ds = pam.dataset.AttrDict(dict(ROOT=str(tmp_path), FOLDERS_ORDER=['Camera0', 'Camera1', 'Camera2'], DATA_FORMAT='*.jpg'))
+    files = LoadFilenames(ds)
+    loader = FrameLoader('Shelf', files, indices=range(2, 11), workers=4, depth=3)
+    seen = []
+    for idx, imgs, ts in loader:
+        ref, ts_ref = LoadImages('Shelf', files[idx])
+        assert ts == ts_ref and len(imgs) == 3
+        for a, b in zip(imgs, ref):
+            assert a.dtype == np.uint8 and np.array_equal(a, b)
+        seen.append(idx)
+    loader.close()
+    assert seen == list(range(2, 11))                 # order preserved
+
+
 @pytest.mark.gpu
 def test_evalmodel_loop_on_synthetic_dataset(tmp_path, capsys):
     """evalmodel.py's loop end to end: images on disk, calibration pickle, precomputed 2D poses -> result pickle identical to
