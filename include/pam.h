@@ -27,6 +27,7 @@ extern "C" {
 #define PAM_MAX_VIEWS 32    /* per-joint view sets are 32-bit masks */
 #define PAM_MAX_TAPS 16
 #define PAM_EXP_TABLE 64
+#define PAM_YOLO_MAX_CAND 1024 /* boxes above the score threshold kept per image before NMS */
 
 #define PAM_OK 0
 #define PAM_E_ARG (-1)      /* bad argument / capacity */
@@ -156,7 +157,8 @@ int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw
 
 /* ---- HRNet conv stack (a1) as hand-written MFMA kernels -------------------------------------------------------
  * pam_conv2d_nhwc_bf16: NHWC bf16 convolution (KH,KW in {1,3}; stride 1/2; Cin % 8 == 0; Cout % 48 == 0 or % 64 == 0) as an
- * implicit GEMM on v_mfma_f32_16x16x32_bf16 with fused epilogue out = [relu](conv + bias [+ residual]).  w_packed is
+ * implicit GEMM on v_mfma_f32_16x16x32_bf16 with fused epilogue out = act(conv + bias [+ residual]); `relu` is the activation
+ * code: 0 linear, 1 ReLU, 2 leaky ReLU (slope 0.1, Darknet); + 4 = add the residual AFTER the activation (Darknet shortcut).  w_packed is
  * [Cout][Kpad] bf16, k = (ky, kx, cin) flattened, zero-padded to Kpad = roundup(KH*KW*Cin, 64); bias float32 or NULL;
  * residual NHWC bf16 of the output shape or NULL.  tile_cfg < 0 = choose automatically.  w_img (optional, 3x3 stride-1 layers
  * with Cin in {48,64,96,192,384}): the same weights pre-packed as per-chunk LDS images [Cout/BN][Cin/CK][BN][9*CK + pad] (BN =
@@ -171,6 +173,26 @@ int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
 int pam_conv_debug_stamps(void* dev_buf);
 int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, const void* const* terms,
                                const int32_t* shifts, void* out, int N, int H, int W, int C, int relu);
+
+/* ---- person detector side (ivclabpose.py:116-120 constructs backend.YOLOv3, :183-204 PersonDetect calls it).
+ * The backend is absent from the reference tree; these follow the public Darknet YOLOv3 definition (parity unpinned).
+ * pam_resize_frames: n BGR uint8 frames (dev array of dev pointers, H x W x 3) -> bilinear (cv2.resize INTER_LINEAR
+ * semantics) out_h x out_w, BGR->RGB, /255, bf16 NHWC with 8 channels (RGB + 5 zeros).
+ * pam_upsample_concat_nhwc_bf16: Darknet `upsample` + `route`: out[n,y,x] = concat(a[n,y/2,x/2,:Ca], b[n,y,x,:Cb]).
+ * pam_yolo_detect: the three `yolo` heads (NHWC bf16, anchor-major channels [tx,ty,tw,th,obj,cls...] x 3, channel
+ * stride chan_stride[h] >= 3*(5+num_classes)) -> per image the boxes of class `class_id` with
+ * sigmoid(obj)*sigmoid(cls) > score_thresh, greedy NMS (IoU > nms_thresh suppressed, best score first, ties to the
+ * lower candidate number: head, then cell row-major, then anchor), at most max_det rows (x1, y1, x2, y2, score) in
+ * frame pixels (float32) into dev_out[n_img][max_det][5]; dev_count[i] = rows kept, dev_count[n_img + i] = boxes above
+ * the threshold before NMS (only the first PAM_YOLO_MAX_CAND of them, in candidate order, enter NMS).
+ * anchors: [head][anchor][w, h] in network-input pixels (18 floats, host memory). */
+int pam_resize_frames(void* stream, int n, const void* const* dev_frames, int frame_h, int frame_w,
+                      int out_h, int out_w, void* dev_out_bf16);
+int pam_upsample_concat_nhwc_bf16(void* stream, const void* a, const void* b, void* out, int N, int H, int W, int Ca, int Cb);
+int pam_yolo_detect(void* stream, int n_img, const void* const* heads /*host array of 3 dev ptrs*/, const int32_t* grid_h,
+                    const int32_t* grid_w, const int32_t* chan_stride, const float* anchors, int net_w, int net_h,
+                    int num_classes, int class_id, float score_thresh, float nms_thresh, int frame_w, int frame_h,
+                    int max_det, float* dev_out, int32_t* dev_count);
 
 #ifdef __cplusplus
 }

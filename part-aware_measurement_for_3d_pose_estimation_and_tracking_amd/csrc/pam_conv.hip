@@ -15,6 +15,15 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;     // 8 bf16 = one MF
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// fused epilogue activation.  act & 3: 0 linear, 1 ReLU, 2 leaky ReLU (slope 0.1); act & 4: the residual is added AFTER the
+// activation (Darknet shortcut layers) instead of before it (ResNet / HRNet blocks)
+__device__ __forceinline__ float epi_act1(float v, int kind) {
+    return kind == 1 ? fmaxf(v, 0.0f) : (kind == 2 ? (v > 0.0f ? v : 0.1f * v) : v);
+}
+__device__ __forceinline__ float epi_act(float v, float r, int act) {
+    return (act & 4) ? epi_act1(v, act & 3) + r : epi_act1(v + r, act & 3);
+}
+
 struct ConvArgs {
     const uint16_t* in; const uint16_t* w; const float* bias; const uint16_t* res; uint16_t* out;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu, Ktot, Kpad, M;
@@ -182,14 +191,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
             const f32x4 v1 = *(const f32x4*)(Ew + px * P + c8 * 8 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             const size_t o = (size_t)m * a.Cout + cw0 + c8 * 8;
+            float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (a.res) {
                 const bf16x8 rr = *(const bf16x8*)(a.res + o);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32((uint16_t)rr[k]);
+                for (int k = 0; k < 8; ++k) rv[k] = bf16_to_f32((uint16_t)rr[k]);
             }
             bf16x8 ov;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ov[k] = (short)f32_to_bf16_rne(a.relu ? fmaxf(v[k], 0.0f) : v[k]);
+            for (int k = 0; k < 8; ++k) ov[k] = (short)f32_to_bf16_rne(epi_act(v[k], rv[k], a.relu));
             *(bf16x8*)(a.out + o) = ov;
         }
     }
@@ -431,9 +441,7 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][j][r] + bias4[j][r];
-                    if (a.res) v[r] += bf16_to_f32((uint16_t)rr[r]);
-                    if (a.relu) v[r] = fmaxf(v[r], 0.0f);
+                    v[r] = epi_act(acc[i][j][r] + bias4[j][r], a.res ? bf16_to_f32((uint16_t)rr[r]) : 0.0f, a.relu);
                 }
                 u32x2 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *(u32x2*)(a.out + o + j * 16) = ov;
@@ -522,7 +530,11 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
         if (c.TH * (W + 2) > 16 * (cfg / 10) * (cfg % 10)) return PAM_E_ARG;
         c.tiles_y = (H + c.TH - 1) / c.TH;
         hipStream_t s = (hipStream_t)stream;
-        switch (Cin * 10 + ntw) {
+        // rows too wide for the patch-in-LDS kernel (e.g. the detector's 208-wide layers): the generic kernel takes them
+        const int npatch = (c.TH + 2) * (W + 2), pmax = (cfg == 44) ? 416 : (cfg == 43 ? 352 : 288);
+        const bool fits = npatch <= pmax && c3_lds_bytes(Cin, ntw, npatch) <= 150 * 1024;
+        if (!fits && tile_cfg >= 100) return PAM_E_ARG;
+        if (fits) switch (Cin * 10 + ntw) {
             case 483: return launch_c3<48, 3>(s, c, cfg);
             case 643: return launch_c3<64, 3>(s, c, cfg);
             case 963: return launch_c3<96, 3>(s, c, cfg);
@@ -537,8 +549,8 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
             case 3842: return launch_c3<384, 2>(s, c, cfg);
             case 1921: return launch_c3<192, 1>(s, c, cfg);
             case 3841: return launch_c3<384, 1>(s, c, cfg);
+            default: return PAM_E_ARG;
         }
-        return PAM_E_ARG;
     }
     if (tile_cfg >= 100) tile_cfg = -1;
     return (Cout % 48 == 0) ? dispatch_conv<3>((hipStream_t)stream, a, tile_cfg) : dispatch_conv<4>((hipStream_t)stream, a, tile_cfg);

@@ -1,0 +1,201 @@
+// libpam_hip.so, person-detector side: what `backend.YOLOv3` does around its conv stack for
+// ivclabpose.PersonDetect (/root/reference/src/ivclabpose.py:116-120,183-204; the backend itself is not in the reference
+// tree, so these follow the public Darknet YOLOv3 definition -- parity unpinned).  The Darknet-53 convolutions run on
+// pam_conv.hip; the kernels here are the HBM-bound streaming pieces: frame resize, route(upsample, skip) and the
+// three-scale box decode + greedy NMS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pam.h"
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+// ---- whole-frame resize -------------------------------------------------------------------------------------------
+// One thread per output pixel: bilinear (half-pixel centres, border replicate = cv2.resize INTER_LINEAR) from the BGR
+// uint8 frame, BGR->RGB, /255, stored as 8-channel bf16 NHWC (RGB + 5 zero channels: the conv kernels want Cin % 8 == 0).
+__global__ __launch_bounds__(256) void k_resize_frames(int n, const uint8_t* const* __restrict__ frames, int H, int W,
+                                                       int oh, int ow, uint16_t* __restrict__ out) {
+    const int img_i = blockIdx.y;
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img_i >= n || px >= oh * ow) return;
+    const int oy = px / ow, ox = px - oy * ow;
+    const uint8_t* __restrict__ img = frames[img_i];
+    float sx = (ox + 0.5f) * ((float)W / (float)ow) - 0.5f;
+    float sy = (oy + 0.5f) * ((float)H / (float)oh) - 0.5f;
+    sx = fminf(fmaxf(sx, 0.0f), (float)(W - 1));
+    sy = fminf(fmaxf(sy, 0.0f), (float)(H - 1));
+    const int x0 = (int)sx, y0 = (int)sy;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float fx = sx - (float)x0, fy = sy - (float)y0;
+    const uint8_t* r0 = img + ((size_t)y0 * W) * 3;
+    const uint8_t* r1 = img + ((size_t)y1 * W) * 3;
+    uint16_t o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {          // c indexes RGB; source is BGR
+        const int sc = 2 - c;
+        const float a = (float)r0[x0 * 3 + sc], b = (float)r0[x1 * 3 + sc];
+        const float cc = (float)r1[x0 * 3 + sc], d = (float)r1[x1 * 3 + sc];
+        const float top = a + (b - a) * fx, bot = cc + (d - cc) * fx;
+        o[c] = f32_to_bf16((top + (bot - top) * fy) * (1.0f / 255.0f));
+    }
+    uint4 v;
+    v.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16); v.y = (uint32_t)o[2]; v.z = 0; v.w = 0;
+    *(uint4*)(out + (((size_t)img_i * oh + oy) * ow + ox) * 8) = v;
+}
+
+extern "C" int pam_resize_frames(void* stream, int n, const void* const* dev_frames, int frame_h, int frame_w,
+                                 int out_h, int out_w, void* dev_out_bf16) {
+    if (n < 0 || !dev_frames || !dev_out_bf16 || frame_h <= 0 || frame_w <= 0 || out_h <= 0 || out_w <= 0) return PAM_E_ARG;
+    if (n == 0) return PAM_OK;
+    dim3 grid((out_h * out_w + 255) / 256, n);
+    hipLaunchKernelGGL(k_resize_frames, grid, dim3(256), 0, (hipStream_t)stream, n, (const uint8_t* const*)dev_frames,
+                       frame_h, frame_w, out_h, out_w, (uint16_t*)dev_out_bf16);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+// ---- route(upsample x2, skip): out[n,y,x,:] = concat(a[n, y/2, x/2, :Ca], b[n, y, x, :Cb]); 16 B per thread -----------
+__global__ __launch_bounds__(256) void k_upsample_concat(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                         uint16_t* __restrict__ out, int N, int H, int W, int Ca, int Cb) {
+    const int C8 = (Ca + Cb) >> 3;
+    const size_t total = (size_t)N * H * W * C8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const size_t p = i / C8;
+        const int x = (int)(p % W);
+        const size_t q = p / W;
+        const int y = (int)(q % H), n = (int)(q / H);
+        const int c = c8 * 8;
+        uint4 v;
+        if (c < Ca) v = *(const uint4*)(a + (((size_t)n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * Ca + c);
+        else        v = *(const uint4*)(b + p * Cb + (c - Ca));
+        *(uint4*)(out + p * (Ca + Cb) + c) = v;
+    }
+}
+
+extern "C" int pam_upsample_concat_nhwc_bf16(void* stream, const void* a, const void* b, void* out, int N, int H, int W,
+                                             int Ca, int Cb) {
+    if (!a || !b || !out || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Ca % 8 != 0 || Cb % 8 != 0 || Ca <= 0 || Cb <= 0)
+        return PAM_E_ARG;
+    const size_t total = (size_t)N * H * W * ((Ca + Cb) / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_upsample_concat, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a,
+                       (const uint16_t*)b, (uint16_t*)out, N, H, W, Ca, Cb);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+// ---- YOLO head decode + greedy NMS for one class --------------------------------------------------------------------
+// One workgroup per image.  Candidates are numbered head-major, then cell (row-major), then anchor.  Pass 1 keeps, in
+// that order, every candidate with sigmoid(objectness) * sigmoid(class logit) > score_thresh (ordered ballot/prefix
+// compaction into LDS, at most PAM_YOLO_MAX_CAND); pass 2 is the classic greedy NMS: repeatedly take the best surviving
+// score (ties: lowest candidate number), emit it, and drop every survivor whose IoU with it exceeds nms_thresh.
+#define DET_T 1024
+struct YoloArgs {
+    const uint16_t* head[3];
+    int gh[3], gw[3], cs[3];
+    float anchors[18];          // [head][anchor][w, h] in network-input pixels
+    int net_w, net_h, nc, cls;
+    float score_thresh, nms_thresh;
+    int frame_w, frame_h, max_det;
+    float* out; int* count;
+    int n_img;
+};
+struct DBest { float v; int i; };
+__device__ __forceinline__ DBest dbetter(DBest a, DBest b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(DET_T) void k_yolo_detect(YoloArgs a) {
+    __shared__ float cx1[PAM_YOLO_MAX_CAND], cy1[PAM_YOLO_MAX_CAND], cx2[PAM_YOLO_MAX_CAND], cy2[PAM_YOLO_MAX_CAND], csc[PAM_YOLO_MAX_CAND];
+    __shared__ int wtot[DET_T / 64];
+    __shared__ DBest red[DET_T / 64];
+    __shared__ int s_running;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per[3] = {a.gh[0] * a.gw[0] * 3, a.gh[1] * a.gw[1] * 3, a.gh[2] * a.gw[2] * 3};
+    const int total = per[0] + per[1] + per[2];
+    const int stride_a = 5 + a.nc;
+    if (tid == 0) s_running = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += DET_T) {
+        const int q = base + tid;
+        bool keep = false;
+        float bx1 = 0, by1 = 0, bx2 = 0, by2 = 0, sc = 0;
+        if (q < total) {
+            int h = 0, r = q;
+            if (r >= per[0]) { r -= per[0]; h = 1; if (r >= per[1]) { r -= per[1]; h = 2; } }
+            const int cell = r / 3, an = r - cell * 3;
+            const int gy = cell / a.gw[h], gx = cell - gy * a.gw[h];
+            const uint16_t* p = a.head[h] + (((size_t)img * a.gh[h] + gy) * a.gw[h] + gx) * a.cs[h] + an * stride_a;
+            sc = sigmoidf_(bf16_to_f32(p[4])) * sigmoidf_(bf16_to_f32(p[5 + a.cls]));
+            if (sc > a.score_thresh) {
+                keep = true;
+                const float bx = (sigmoidf_(bf16_to_f32(p[0])) + (float)gx) / (float)a.gw[h];
+                const float by = (sigmoidf_(bf16_to_f32(p[1])) + (float)gy) / (float)a.gh[h];
+                const float bw = expf(bf16_to_f32(p[2])) * a.anchors[(h * 3 + an) * 2 + 0] / (float)a.net_w;
+                const float bh = expf(bf16_to_f32(p[3])) * a.anchors[(h * 3 + an) * 2 + 1] / (float)a.net_h;
+                bx1 = (bx - 0.5f * bw) * (float)a.frame_w; bx2 = (bx + 0.5f * bw) * (float)a.frame_w;
+                by1 = (by - 0.5f * bh) * (float)a.frame_h; by2 = (by + 0.5f * bh) * (float)a.frame_h;
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wtot[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_running;
+        for (int w = 0; w < wave; ++w) off += wtot[w];
+        off += __popcll(m & ((1ull << lane) - 1ull));
+        if (keep && off < PAM_YOLO_MAX_CAND) { cx1[off] = bx1; cy1[off] = by1; cx2[off] = bx2; cy2[off] = by2; csc[off] = sc; }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < DET_T / 64; ++w) t += wtot[w]; s_running += t; }
+        __syncthreads();
+    }
+    const int nfound = s_running;
+    const int ncand = nfound < PAM_YOLO_MAX_CAND ? nfound : PAM_YOLO_MAX_CAND;
+    // greedy NMS; one candidate per thread (PAM_YOLO_MAX_CAND == DET_T)
+    bool alive = tid < ncand;
+    const float mx1 = alive ? cx1[tid] : 0, my1 = alive ? cy1[tid] : 0, mx2 = alive ? cx2[tid] : 0, my2 = alive ? cy2[tid] : 0;
+    const float marea = (mx2 - mx1) * (my2 - my1);
+    int kept = 0;
+    while (kept < a.max_det) {
+        DBest b; b.v = alive ? csc[tid] : -1.0f; b.i = tid;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { DBest t; t.v = __shfl_xor(b.v, o, 64); t.i = __shfl_xor(b.i, o, 64); b = dbetter(b, t); }
+        if (lane == 0) red[wave] = b;
+        __syncthreads();
+        b = red[0];
+#pragma unroll
+        for (int w = 1; w < DET_T / 64; ++w) b = dbetter(b, red[w]);
+        if (b.v < 0.0f) break;                                   // uniform: every thread reads the same red[]
+        const float kx1 = cx1[b.i], ky1 = cy1[b.i], kx2 = cx2[b.i], ky2 = cy2[b.i];
+        if (tid == 0) {
+            float* row = a.out + ((size_t)img * a.max_det + kept) * 5;
+            row[0] = kx1; row[1] = ky1; row[2] = kx2; row[3] = ky2; row[4] = b.v;
+        }
+        if (alive) {
+            const float iw = fminf(mx2, kx2) - fmaxf(mx1, kx1), ih = fminf(my2, ky2) - fmaxf(my1, ky1);
+            const float inter = (iw > 0.0f && ih > 0.0f) ? iw * ih : 0.0f;
+            const float uni = marea + (kx2 - kx1) * (ky2 - ky1) - inter;
+            if (tid == b.i || inter > a.nms_thresh * uni) alive = false;
+        }
+        ++kept;
+        __syncthreads();                                         // red[] is rewritten next round
+    }
+    if (tid == 0) { a.count[img] = kept; a.count[a.n_img + img] = nfound; }
+}
+
+extern "C" int pam_yolo_detect(void* stream, int n_img, const void* const* heads, const int32_t* grid_h, const int32_t* grid_w,
+                               const int32_t* chan_stride, const float* anchors, int net_w, int net_h, int num_classes,
+                               int class_id, float score_thresh, float nms_thresh, int frame_w, int frame_h, int max_det,
+                               float* dev_out, int32_t* dev_count) {
+    if (n_img < 0 || !heads || !grid_h || !grid_w || !chan_stride || !anchors || !dev_out || !dev_count || num_classes <= 0 ||
+        class_id < 0 || class_id >= num_classes || max_det <= 0 || net_w <= 0 || net_h <= 0)
+        return PAM_E_ARG;
+    if (n_img == 0) return PAM_OK;
+    YoloArgs a;
+    for (int h = 0; h < 3; ++h) {
+        if (!heads[h] || grid_h[h] <= 0 || grid_w[h] <= 0 || chan_stride[h] < 3 * (5 + num_classes)) return PAM_E_ARG;
+        a.head[h] = (const uint16_t*)heads[h]; a.gh[h] = grid_h[h]; a.gw[h] = grid_w[h]; a.cs[h] = chan_stride[h];
+    }
+    for (int i = 0; i < 18; ++i) a.anchors[i] = anchors[i];
+    a.net_w = net_w; a.net_h = net_h; a.nc = num_classes; a.cls = class_id; a.score_thresh = score_thresh; a.nms_thresh = nms_thresh;
+    a.frame_w = frame_w; a.frame_h = frame_h; a.max_det = max_det; a.out = dev_out; a.count = dev_count; a.n_img = n_img;
+    hipLaunchKernelGGL(k_yolo_detect, dim3(n_img), dim3(DET_T), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}

@@ -191,8 +191,7 @@ def algorithmic_work(n_crops, resolution=(384, 288)):
         def __getattr__(self, name):
             return lambda *a, **k: 0
     eng = HipHRNet.__new__(HipHRNet)
-    eng.lib = _MetaLib(); eng.device = torch.device('meta'); eng.tile_cfg = -1; eng.multi_stream = False; eng.groups = 1
-    eng.max_groups = 1
+    eng.lib = _MetaLib(); eng.device = torch.device('meta'); eng.tile_cfg = -1; eng.multi_stream = False
     model = fold_batchnorm(PoseHighResolutionNet())
     model.final_layer = nn.Identity()
     HipHRNet._pack(eng, model, torch.device('meta'))

@@ -15,19 +15,26 @@ from . import hrnet as H
 
 
 class PackedConv(object):
-    def __init__(self, conv, device, pad_cin_to=None):
+    def __init__(self, conv, device, pad_cin_to=None, pad_cout_to=None):
+        """Zero-padding input channels (pad_cin_to) or output channels (pad_cout_to: zero filters, zero bias) leaves the real
+        channels unchanged; the detector uses it for Darknet's 3-, 32- and 255-channel layers."""
         w = conv.weight.detach().float()
+        b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0])
         cout, cin, kh, kw = w.shape
         if pad_cin_to is not None and cin < pad_cin_to:
             w = torch.cat([w, torch.zeros(cout, pad_cin_to - cin, kh, kw)], dim=1)
             cin = pad_cin_to
+        if pad_cout_to is not None and cout < pad_cout_to:
+            w = torch.cat([w, torch.zeros(pad_cout_to - cout, cin, kh, kw)], dim=0)
+            b = torch.cat([b, torch.zeros(pad_cout_to - cout)])
+            cout = pad_cout_to
         assert cin % 8 == 0 and (cout % 48 == 0 or cout % 64 == 0), (cin, cout)
         ktot = kh * kw * cin
         kpad = (ktot + 63) // 64 * 64
         wp = torch.zeros((cout, kpad), dtype=torch.float32)
         wp[:, :ktot] = w.permute(0, 2, 3, 1).reshape(cout, ktot)          # k = (ky, kx, cin), cin fastest
         self.w = wp.to(torch.bfloat16).to(device).contiguous()
-        self.bias = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(cout)).to(device).contiguous()
+        self.bias = b.to(device).contiguous()
         self.cin, self.cout, self.kh, self.kw = cin, cout, kh, kw
         self.stride, self.pad = conv.stride[0], conv.padding[0]
         # per-chunk LDS images for k_conv3x3, built lazily per slab width (the kernel picks the slab from the layer's H x W)
@@ -54,27 +61,94 @@ class PackedConv(object):
         return img
 
 
-class HipHRNet(object):
+class ConvEngine(object):
+    """Kernel launchers shared by the pose network (HipHRNet) and the person detector (yolov3.HipDarknet)."""
+    count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
+    tile_cfg = -1
+    _keep = None
+    ACT = {None: 0, False: 0, True: 1, 'linear': 0, 'relu': 1, 'leaky': 2}
+
+    def conv(self, op, x, res=None, relu=False, res_after_act=False):
+        """relu: False/True, or 'linear' | 'relu' | 'leaky' (slope 0.1); res_after_act: out = act(conv + b) + res (Darknet shortcut)."""
+        n, cin, h, w = x.shape
+        assert cin == op.cin and x.is_contiguous(memory_format=torch.channels_last), (x.shape, op.cin)
+        ho = (h + 2 * op.pad - op.kh) // op.stride + 1
+        wo = (w + 2 * op.pad - op.kw) // op.stride + 1
+        y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        if self._keep is not None:
+            self._keep.append(y)
+        if self.count is not None:       # unique bytes this conv must move: input + weights + bias [+ residual] + output
+            self.count['bytes'] += 2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin + (y.numel() if res is not None else 0)) + 4 * op.cout
+            self.count['flops'] += 2 * y.numel() * op.kh * op.kw * op.cin
+            self.count['launches'] += 1
+        if x.device.type == 'meta':
+            return y
+        act = self.ACT[relu] | (4 if (res_after_act and res is not None) else 0)
+        wimg = op.image(h, w)
+        st = torch.cuda.current_stream(x.device).cuda_stream
+        rc = self.lib.pam_conv2d_nhwc_bf16(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
+                                           C.c_void_p(wimg.data_ptr()) if wimg is not None else None,
+                                           C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
+                                           C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad,
+                                           act, self.tile_cfg)
+        if rc != 0:
+            raise _lib.PamError('pam_conv2d_nhwc_bf16 failed (%d) for %s' % (rc, (x.shape, op.cout, op.kh, op.stride)))
+        return y
+
+    def upsample_add(self, base, terms, shifts, relu):
+        n, c, h, w = base.shape
+        y = torch.empty_like(base)
+        if self._keep is not None:
+            self._keep.append(y)
+        if self.count is not None:
+            self.count['bytes'] += 2 * (2 * base.numel() + sum(t.numel() for t in terms))
+            self.count['launches'] += 1
+        if base.device.type == 'meta':
+            return y
+        st = torch.cuda.current_stream(base.device).cuda_stream
+        ptrs = (C.c_void_p * 3)(*[C.c_void_p(t.data_ptr()) for t in terms] + [None] * (3 - len(terms)))
+        sh = (C.c_int32 * 3)(*(list(shifts) + [0] * (3 - len(shifts))))
+        rc = self.lib.pam_upsample_add_nhwc_bf16(C.c_void_p(st), C.c_void_p(base.data_ptr()), len(terms), ptrs, sh,
+                                                 C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0)
+        if rc != 0:
+            raise _lib.PamError('pam_upsample_add_nhwc_bf16 failed (%d)' % rc)
+        return y
+
+    def upsample_concat(self, a, b):
+        """Darknet upsample(x2) + route: concat(nearest_up2(a), b) along channels."""
+        n, ca, h2, w2 = a.shape
+        _, cb, h, w = b.shape
+        assert h == 2 * h2 and w == 2 * w2 and b.shape[0] == n, (a.shape, b.shape)
+        y = torch.empty((n, ca + cb, h, w), dtype=torch.bfloat16, device=a.device, memory_format=torch.channels_last)
+        if self._keep is not None:
+            self._keep.append(y)
+        if self.count is not None:
+            self.count['bytes'] += 2 * (a.numel() + b.numel() + y.numel())
+            self.count['launches'] += 1
+        if a.device.type == 'meta':
+            return y
+        st = torch.cuda.current_stream(a.device).cuda_stream
+        rc = self.lib.pam_upsample_concat_nhwc_bf16(C.c_void_p(st), C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
+                                                    C.c_void_p(y.data_ptr()), n, h, w, ca, cb)
+        if rc != 0:
+            raise _lib.PamError('pam_upsample_concat_nhwc_bf16 failed (%d)' % rc)
+        return y
+
+
+class HipHRNet(ConvEngine):
     # 'barrier': branch streams join/fork through the caller's stream after every stage (hipGraph-capturable);
     # 'events': pairwise event dependencies (eager only: hipGraph capture of that pattern crashes in ROCm 7.2 at capture end)
     sync_mode = os.environ.get('PAM_HRNET_SYNC', 'barrier')
-    count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
-    tile_cfg = -1
     multi_stream = False
-    groups = 1
-    max_groups = 1
 
     def __init__(self, folded_model, device):
         self.lib = _lib.load()
         self.device = device
         self._pack(folded_model, device)
         self.tile_cfg = -1
-        # concurrency: the 2-4 branches of an HR module run on side streams; the crop batch can additionally be split into
-        # `groups` independent sub-batches, each with its own stream set (the kernels are latency-bound, not chip-filling)
-        self.side_streams = [[torch.cuda.Stream(device) for _ in range(3)]]
-        self.side = self.side_streams[0]
+        # concurrency: the 2-4 branches of an HR module run on side streams (the coarse branches do not fill the chip)
+        self.side = [torch.cuda.Stream(device) for _ in range(3)]
         self.multi_stream = True
-        self.groups = 1
         self.count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
 
     def _pack(self, folded_model, device):
@@ -106,51 +180,6 @@ class HipHRNet(object):
                     r.append(('down', [P(step[0]) for step in f]))
             fuse.append(r)
         return dict(branches=branches, fuse=fuse)
-
-    # -- kernel launches -----------------------------------------------------------------------------------------------
-    def conv(self, op, x, res=None, relu=False):
-        n, cin, h, w = x.shape
-        assert cin == op.cin and x.is_contiguous(memory_format=torch.channels_last), (x.shape, op.cin)
-        ho = (h + 2 * op.pad - op.kh) // op.stride + 1
-        wo = (w + 2 * op.pad - op.kw) // op.stride + 1
-        y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-        if getattr(self, '_keep', None) is not None:
-            self._keep.append(y)
-        if self.count is not None:       # unique bytes this conv must move: input + weights + bias [+ residual] + output
-            self.count['bytes'] += 2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin + (y.numel() if res is not None else 0)) + 4 * op.cout
-            self.count['flops'] += 2 * y.numel() * op.kh * op.kw * op.cin
-            self.count['launches'] += 1
-        if x.device.type == 'meta':
-            return y
-        wimg = op.image(h, w)
-        st = torch.cuda.current_stream(x.device).cuda_stream
-        rc = self.lib.pam_conv2d_nhwc_bf16(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
-                                           C.c_void_p(wimg.data_ptr()) if wimg is not None else None,
-                                           C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
-                                           C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad,
-                                           1 if relu else 0, self.tile_cfg)
-        if rc != 0:
-            raise _lib.PamError('pam_conv2d_nhwc_bf16 failed (%d) for %s' % (rc, (x.shape, op.cout, op.kh, op.stride)))
-        return y
-
-    def upsample_add(self, base, terms, shifts, relu):
-        n, c, h, w = base.shape
-        y = torch.empty_like(base)
-        if getattr(self, '_keep', None) is not None:
-            self._keep.append(y)
-        if self.count is not None:
-            self.count['bytes'] += 2 * (2 * base.numel() + sum(t.numel() for t in terms))
-            self.count['launches'] += 1
-        if base.device.type == 'meta':
-            return y
-        st = torch.cuda.current_stream(base.device).cuda_stream
-        ptrs = (C.c_void_p * 3)(*[C.c_void_p(t.data_ptr()) for t in terms] + [None] * (3 - len(terms)))
-        sh = (C.c_int32 * 3)(*(list(shifts) + [0] * (3 - len(shifts))))
-        rc = self.lib.pam_upsample_add_nhwc_bf16(C.c_void_p(st), C.c_void_p(base.data_ptr()), len(terms), ptrs, sh,
-                                                 C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0)
-        if rc != 0:
-            raise _lib.PamError('pam_upsample_add_nhwc_bf16 failed (%d)' % rc)
-        return y
 
     # -- network ------------------------------------------------------------------------------------------------------
     # Stream plan: branch b of every HR module, and fuse output b, always run on stream b (stream 0 = the caller's stream);
@@ -224,7 +253,6 @@ class HipHRNet(object):
     def features(self, x8):
         """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
         self._keep = []
-        self.side = self.side_streams[0] if hasattr(self, 'side_streams') else None
         return self._features(x8)
 
     def _features(self, x8):

@@ -77,9 +77,21 @@ class ivclabpose(object):
         self.pose_model = None
         if self.person_detector is None:
             print("Person Detector : Close.")
+        elif _cfg(self.person_detector, 'NAME') == 'YOLOv3':                        # ivclabpose.py:116-120
+            import os
+            from .yolov3 import YOLOv3
+            d = self.person_detector
+            cfg, weight, names = _cfg(d, 'CFG'), _cfg(d, 'WEIGHT'), _cfg(d, 'CLASS_NAMES')
+            # the reference's cfg / weight / names files are not distributed with it: a missing cfg or names file means
+            # the standard YOLOv3-416 COCO layout (person = class 0), missing weights mean a seeded random network
+            self.bbox_detector = YOLOv3(cfg if cfg and os.path.exists(cfg) else None,
+                                        weight if weight and os.path.exists(weight) else None,
+                                        names if names and os.path.exists(names) else None,
+                                        score_thresh=_cfg(d, 'SCORE_THRESH'), nms_thresh=_cfg(d, 'NMS_THRESH'),
+                                        use_cuda=True, device=device)
+            print("Person Detector : ", _cfg(d, 'NAME'), '(weights: %s)' % self.bbox_detector.weights)
         else:
-            raise NotImplementedError('YOLOv3 person detection is outside this hot path (supply person boxes; '
-                                      'use DETECT_MODEL: None)')
+            raise NotImplementedError('person detector %r' % _cfg(self.person_detector, 'NAME'))
         if self.pose_detector is None:
             print("Pose Detector : Close.")
         elif _cfg(self.pose_detector, 'NAME') == 'HRPose':
@@ -118,7 +130,21 @@ class ivclabpose(object):
         return self.cameras
 
     def PersonDetect(self, imglist, image_id):
-        return None
+        """ivclabpose.py:183-204: per image a list of person dicts, boxes clamped to the image, xywh."""
+        if self.person_detector is None or _cfg(self.person_detector, 'NAME') != 'YOLOv3':
+            return None
+        person_bbox_list = []
+        results = self.bbox_detector(imglist)
+        for idx, result in enumerate(results):
+            h, w = imglist[idx].shape[:2]
+            person_temps = []
+            for ret in result:
+                x1, y1 = max(0, float(ret[0])), max(0, float(ret[1]))
+                x2, y2 = min(float(ret[2]), w), min(float(ret[3]), h)
+                person_temps.append(dict(image_id=image_id, category_id=1, score=float(round(float(ret[4]), 4)),
+                                         bbox=[x1, y1, x2 - x1, y2 - y1], data=imglist[idx], feature=[]))
+            person_bbox_list.append(person_temps)
+        return person_bbox_list
 
     def PersonPoseDetect(self, imagelist=None, person_bbox_list=None, batch_size=20, image_id=None):
         if self.pose_model is None:

@@ -2,7 +2,8 @@
 """Demo driver with the reference's CLI (/root/reference/src/testmodel.py): ``python testmodel.py --dataset Shelf``.
 
 Per frame: load C images -> person boxes -> HRNet 2D poses -> PersonTrack_Project3DPose, with the reference's timing
-print-out.  YOLOv3 is outside this build: boxes (and optionally 2D poses) come from ``DATASET.PRECOMPUTED`` -- a pickle
+print-out.  Boxes come from PersonDetect when ``DETECT_MODEL: YOLOv3`` (testmodel.py:56-58), else -- ``DETECT_MODEL: None``,
+the shipped default -- boxes (and optionally 2D poses) come from ``DATASET.PRECOMPUTED``, a pickle
 {frame_id: [per view list of {'bbox': [x,y,w,h], optional 'keypoints', 'keypoints_score'}]} -- see INTEGRATION.md."""
 import argparse
 import os
@@ -31,17 +32,23 @@ def build_model(cfg):
 
 
 def frame_inputs(model, precomputed, frame_id, imagelist):
-    """person_bbox_list + dump_result_list for one frame from the precomputed store (boxes, optionally 2D poses)."""
-    views = precomputed.get(frame_id, [[] for _ in imagelist])
-    pbl = [[dict(image_id=frame_id, category_id=1, score=float(p.get('score', 1.0)), bbox=list(p['bbox']),
-                 data=imagelist[v], feature=[]) for p in persons] for v, persons in enumerate(views)]
-    if all('keypoints' in p for persons in views for p in persons):
-        dump = [[dict(bbox=list(p['bbox']), keypoints=list(p['keypoints']), keypoints_score=list(p['keypoints_score']),
-                      feature=[]) for p in persons] for persons in views]
-        return pbl, dump, 0.0
+    """person_bbox_list + dump_result_list for one frame -> (pbl, dump, detect seconds, pose seconds)."""
+    dt_det = 0.0
+    if model.person_detector is not None:                    # testmodel.py:56-58
+        t0 = time.time()
+        pbl = model.PersonDetect(imagelist, frame_id)
+        dt_det = time.time() - t0
+    else:
+        views = precomputed.get(frame_id, [[] for _ in imagelist])
+        pbl = [[dict(image_id=frame_id, category_id=1, score=float(p.get('score', 1.0)), bbox=list(p['bbox']),
+                     data=imagelist[v], feature=[]) for p in persons] for v, persons in enumerate(views)]
+        if all('keypoints' in p for persons in views for p in persons):
+            dump = [[dict(bbox=list(p['bbox']), keypoints=list(p['keypoints']), keypoints_score=list(p['keypoints_score']),
+                          feature=[]) for p in persons] for persons in views]
+            return pbl, dump, 0.0, 0.0
     t0 = time.time()
     dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
-    return pbl, dump, time.time() - t0
+    return pbl, dump, dt_det, time.time() - t0
 
 
 def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
@@ -49,17 +56,19 @@ def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
     os.makedirs(cfg.OUTPUT, exist_ok=True)
     with open(os.path.join(dataset.ROOT, dataset.CALIBRATION_FILE), 'rb') as f:
         camera_parameter = pickle.load(f)
-    with open(os.path.join(dataset.ROOT, dataset.PRECOMPUTED), 'rb') as f:
-        precomputed = pickle.load(f)
     model, build3D = build_model(cfg)
-    t_pose = t_track = 0.0
+    precomputed = {}
+    if model.person_detector is None:
+        with open(os.path.join(dataset.ROOT, dataset.PRECOMPUTED), 'rb') as f:
+            precomputed = pickle.load(f)
+    t_det = t_pose = t_track = 0.0
     start, end = dataset.TEST_RANGE
     n_views = len(dataset.FOLDERS_ORDER)
     loader = FrameLoader(dataset.TEST_DATASET, inputs, indices=range(start, end), workers=int(dataset.get('LOADER_THREADS', 8)))
     for i, (frame_id, imagelist, timestamp) in enumerate(loader):     # decoded a few frames ahead on worker threads
         if i == 0:
             model.GetCameraParameters(camera_parameter, imagelist[0].shape[0], imagelist[0].shape[1])
-        pbl, dump, dt_pose = frame_inputs(model, precomputed, frame_id, imagelist)
+        pbl, dump, dt_det, dt_pose = frame_inputs(model, precomputed, frame_id, imagelist)
         result = None
         dt_track = 0.0
         if any(len(v) for v in dump):                       # testmodel.py:66 guard: no pose in any view -> frame skipped
@@ -69,14 +78,15 @@ def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
         if on_frame is not None:
             on_frame(frame_id, timestamp, result)
         if frame_id > start + 10:
+            t_det += dt_det
             t_pose += dt_pose
             t_track += dt_track
     loader.close()
     n = max(1, end - start - 10)
-    print("Person Detect Processing time (s/f): %f" % 0.0)
+    print("Person Detect Processing time (s/f): %f" % (t_det / n))
     print("Pose Detect Processing time (s/f): %f" % (t_pose / n))
     print("Track Processing time (s/f): %f" % (t_track / n))
-    print("fps: %f" % (1 / max(1e-12, (t_pose / n) / n_views + t_track / n)))
+    print("fps: %f" % (1 / max(1e-12, (t_det / n + t_pose / n) / n_views + t_track / n)))
     print("tracking fps: %f" % (1 / max(1e-12, t_track / n)))
 
 

@@ -11,7 +11,6 @@ ap.add_argument('--n', type=int, default=20)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--modes', default='graph')
 ap.add_argument('--backends', default='hip,miopen')
-ap.add_argument('--groups', default='1')
 ap.add_argument('--no-branch-streams', action='store_true')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
@@ -33,17 +32,13 @@ def timeit(fn, iters):
 for backend in args.backends.split(','):
     for mode in args.modes.split(','):
         torch.backends.cudnn.benchmark = (mode == 'bench')
-        for grp in [int(q) for q in args.groups.split(',')]:
-            if backend != 'hip' and grp != 1:
-                continue
-            t0 = time.time()
-            net = hrnet.HRNetPose(48, 17, None, use_graph=(mode == 'graph'), backend=backend)
-            if backend == 'hip':
-                net.hip.groups = grp
-                net.hip.multi_stream = not args.no_branch_streams
-            x = net.input_buffer(args.n)
-            x.copy_(torch.randn(x.shape, device=dev).to(x.dtype))
-            net.heatmaps(x); torch.cuda.synchronize()
-            t1 = time.time()
-            ms = timeit(lambda: net.heatmaps(x), args.iters)
-            print(backend, 'groups=%d' % grp, '%-6s N=%d  first-call %.1fs  %.3f ms/forward  %.1f TFLOP/s' % (mode, args.n, t1 - t0, ms, flops / ms / 1e9), flush=True)
+        t0 = time.time()
+        net = hrnet.HRNetPose(48, 17, None, use_graph=(mode == 'graph'), backend=backend)
+        if backend == 'hip':
+            net.hip.multi_stream = not args.no_branch_streams
+        x = net.input_buffer(args.n)
+        x.copy_(torch.randn(x.shape, device=dev).to(x.dtype))
+        net.heatmaps(x); torch.cuda.synchronize()
+        t1 = time.time()
+        ms = timeit(lambda: net.heatmaps(x), args.iters)
+        print(backend, '%-6s N=%d  first-call %.1fs  %.3f ms/forward  %.1f TFLOP/s' % (mode, args.n, t1 - t0, ms, flops / ms / 1e9), flush=True)
