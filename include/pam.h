@@ -161,7 +161,7 @@ int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw
  * code: 0 linear, 1 ReLU, 2 leaky ReLU (slope 0.1, Darknet); + 4 = add the residual AFTER the activation (Darknet shortcut).  w_packed is
  * [Cout][Kpad] bf16, k = (ky, kx, cin) flattened, zero-padded to Kpad = roundup(KH*KW*Cin, 64); bias float32 or NULL;
  * residual NHWC bf16 of the output shape or NULL.  tile_cfg < 0 = choose automatically.  w_img (optional, 3x3 stride-1 layers
- * with Cin in {48,64,96,192,384}): the same weights pre-packed as per-chunk LDS images [Cout/BN][Cin/CK][BN][9*CK + pad] (BN =
+ * with Cin in {48,64,96,128,192,256,384,512}): the same weights pre-packed as per-chunk LDS images [Cout/BN][Cin/CK][BN][9*CK + pad] (BN =
  * pam_conv3x3_slab(H, W, Cin, Cout); CK = 48 if Cin == 48, 64 if Cin >= 192, else 32; row pitch 864 / 1184 / 608 bytes) for the rows-in-LDS kernel k_conv3x3; NULL = generic kernel.
  * pam_upsample_add_nhwc_bf16: the HRNet fuse-layer sum out = [relu](base + sum_t nearest_upsample(term_t, 2^shift_t)). */
 int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,

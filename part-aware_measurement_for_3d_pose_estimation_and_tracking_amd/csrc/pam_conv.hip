@@ -48,7 +48,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // Block tile: BM = 64*WM output pixels x BN = 16*NTW*WN output channels; each wave owns 64 pixels x 16*NTW channels
 // (4 x NTW accumulator tiles of 16x16).  K is walked in chunks of 64; chunk c+1 is fetched (buffer_load, zero-fill by the
 // descriptor's range check, no branches) while chunk c is multiplied out of LDS.
-template <int NTW, int WM, int WN>
+template <int NTW, int WM, int WN, bool GEN>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
     constexpr int T = 64 * WM * WN, BM = 64 * WM, BN = 16 * NTW * WN;
     constexpr int APT = BM * 8 / T;                    // A pieces (16 B) per thread per chunk
@@ -198,8 +198,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
                 for (int k = 0; k < 8; ++k) rv[k] = bf16_to_f32((uint16_t)rr[k]);
             }
             bf16x8 ov;
+            if constexpr (!GEN) {                   // HRNet's codes 0 / 1: their own instantiation, minimal epilogue
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ov[k] = (short)f32_to_bf16_rne(epi_act(v[k], rv[k], a.relu));
+                for (int k = 0; k < 8; ++k) { const float t = v[k] + rv[k]; ov[k] = (short)f32_to_bf16_rne(a.relu ? fmaxf(t, 0.0f) : t); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ov[k] = (short)f32_to_bf16_rne(epi_act(v[k], rv[k], a.relu));
+            }
             *(bf16x8*)(a.out + o) = ov;
         }
     }
@@ -207,10 +212,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
 
 template <int NTW, int WM, int WN>
 static int launch_conv(hipStream_t s, const ConvArgs& a) {
+    constexpr int BM_ = 64 * WM, BN_ = 16 * NTW * WN;
+    if (a.relu > 1) {                                   // Darknet activation codes: the general-epilogue instantiation
+        dim3 grid((a.M + BM_ - 1) / BM_, a.Cout / BN_);
+        const size_t lds = 2 * (size_t)(BM_ + BN_) * ROWB;
+        hipLaunchKernelGGL((k_conv_igemm<NTW, WM, WN, true>), grid, dim3(64 * WM * WN), lds, s, a);
+        return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+    }
     constexpr int BM = 64 * WM, BN = 16 * NTW * WN;
     dim3 grid((a.M + BM - 1) / BM, a.Cout / BN);
     const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-    hipLaunchKernelGGL((k_conv_igemm<NTW, WM, WN>), grid, dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL((k_conv_igemm<NTW, WM, WN, false>), grid, dim3(64 * WM * WN), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
@@ -258,6 +270,8 @@ extern "C" int pam_conv_debug_stamps(void* dev_buf) { g_c3_stamps = (unsigned lo
 // chunk of input channels resident in LDS per K pass: all 48 for Cin = 48 (K walked as the flattened (tap, c) index), 64 for the
 // deep small-image layers (fewer, longer passes hide the load latency), 32 otherwise.  Pitches from tools/lds_sim.py:
 // conflict-free ds_read_b128 needs pitch = 32 (mod 64) bytes for the pixel rows and these row pitches for the weights.
+// widths whose instantiation carries the general (Darknet) activation epilogue; the others take codes 0 / 1 only
+__host__ __device__ constexpr bool c3_general_act(int cin) { return cin == 64 || cin == 128 || cin == 256 || cin == 512; }
 __host__ __device__ constexpr int c3_ck(int cin) { return cin == 48 ? 48 : (cin >= 192 ? 64 : 32); }
 __host__ __device__ constexpr int c3_pitch_a(int cin) { return c3_ck(cin) == 64 ? 160 : 96; }
 __host__ __device__ constexpr int c3_pitch_w(int cin) { return cin == 48 ? 864 : (c3_ck(cin) == 64 ? 1184 : 608); }
@@ -439,9 +453,17 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
             for (int j = 0; j < NTW; ++j) {
                 const bf16x4 rr = __builtin_bit_cast(bf16x4, rres[i][j]);
                 float v[4];
+                if constexpr (!c3_general_act(CIN)) {   // HRNet-only widths: codes 0 / 1, minimal epilogue
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = epi_act(acc[i][j][r] + bias4[j][r], a.res ? bf16_to_f32((uint16_t)rr[r]) : 0.0f, a.relu);
+                    for (int r = 0; r < 4; ++r) {
+                        v[r] = acc[i][j][r] + bias4[j][r];
+                        if (a.res) v[r] += bf16_to_f32((uint16_t)rr[r]);
+                        if (a.relu) v[r] = fmaxf(v[r], 0.0f);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = epi_act(acc[i][j][r] + bias4[j][r], a.res ? bf16_to_f32((uint16_t)rr[r]) : 0.0f, a.relu);
                 }
                 u32x2 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *(u32x2*)(a.out + o + j * 16) = ov;
@@ -489,13 +511,18 @@ static void pick_rows(int N, int H, int W, int Cout, int ntw, int& TH, int& cfg)
     if (TH > H) TH = H;
     // prefer a divisor of H close to the cap (no ragged last tile) when it costs < 15 % of the tile height
     for (int t = TH; t >= 1 && t * 100 >= TH * 85; --t) if (H % t == 0) { TH = t; break; }
+    // wide rows (the detector's 104-wide layers): shrink the tile until its patch fits, then the block to the slots left
+    while (TH > 1 && (TH + 2) * PW > 416) --TH;
+    if (TH * PW <= 128 && (TH + 2) * PW <= 288) cfg = 42;
+    else if (TH * PW <= 192 && (TH + 2) * PW <= 352) cfg = 43;
 }
 
 // output channels per workgroup slab of k_conv3x3 (the host packs the weight images with the same number).  The deep, small
 // images (24x18, 12x9) have too few pixel tiles to fill 256 CUs, so their slabs are narrower: more, shorter workgroups.
 extern "C" int pam_conv3x3_slab(int H, int W, int Cin, int Cout) {
     const int wide = (Cout % 48 == 0) ? 48 : 64;
-    if (Cin < 192 || Cout % 48 != 0) return wide;
+    if (Cin < 192) return wide;
+    if (Cout % 48 != 0) return H * W <= 1024 ? 32 : 64;                            // Darknet's 256- / 512-channel 3x3 layers
     const int env = getenv("PAM_C3_SLAB") ? atoi(getenv("PAM_C3_SLAB")) : 0;      // tuning hook
     if (env == 16 || env == 32 || env == 48) return env;
     return H * W <= 128 ? 16 : (H * W <= 512 ? 32 : 48);
@@ -515,7 +542,7 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
     a.Ktot = KH * KW * Cin; a.Kpad = (a.Ktot + KC - 1) / KC * KC; a.M = N * a.Ho * a.Wo;
     if (H >= 32768 || W >= 32768) return PAM_E_ARG;
     if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&
-        (Cin == 48 || Cin == 64 || Cin == 96 || Cin == 192 || Cin == 384)) {
+        (Cin == 48 || Cin == 64 || Cin == 96 || Cin == 192 || Cin == 384 || Cin == 128 || Cin == 256 || Cin == 512)) {
         const int ntw = pam_conv3x3_slab(H, W, Cin, Cout) / 16;
         C3Args c;
         c.in = a.in; c.wimg = (const uint16_t*)w_img; c.bias = bias; c.res = a.res; c.out = a.out;
@@ -532,7 +559,8 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
         hipStream_t s = (hipStream_t)stream;
         // rows too wide for the patch-in-LDS kernel (e.g. the detector's 208-wide layers): the generic kernel takes them
         const int npatch = (c.TH + 2) * (W + 2), pmax = (cfg == 44) ? 416 : (cfg == 43 ? 352 : 288);
-        const bool fits = npatch <= pmax && c3_lds_bytes(Cin, ntw, npatch) <= 150 * 1024;
+        const bool fits = npatch <= pmax && c3_lds_bytes(Cin, ntw, npatch) <= 150 * 1024 && Cout % (16 * ntw) == 0 &&
+                          (relu <= 1 || c3_general_act(Cin));
         if (!fits && tile_cfg >= 100) return PAM_E_ARG;
         if (fits) switch (Cin * 10 + ntw) {
             case 483: return launch_c3<48, 3>(s, c, cfg);
@@ -549,7 +577,12 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
             case 3842: return launch_c3<384, 2>(s, c, cfg);
             case 1921: return launch_c3<192, 1>(s, c, cfg);
             case 3841: return launch_c3<384, 1>(s, c, cfg);
-            default: return PAM_E_ARG;
+            case 1284: return launch_c3<128, 4>(s, c, cfg);     // Darknet-53 widths
+            case 2564: return launch_c3<256, 4>(s, c, cfg);
+            case 2562: return launch_c3<256, 2>(s, c, cfg);
+            case 5124: return launch_c3<512, 4>(s, c, cfg);
+            case 5122: return launch_c3<512, 2>(s, c, cfg);
+            default: if (tile_cfg >= 100) return PAM_E_ARG;     // no instantiation for this (Cin, slab): generic kernel below
         }
     }
     if (tile_cfg >= 100) tile_cfg = -1;

@@ -39,7 +39,7 @@ class PackedConv(object):
         self.stride, self.pad = conv.stride[0], conv.padding[0]
         # per-chunk LDS images for k_conv3x3, built lazily per slab width (the kernel picks the slab from the layer's H x W)
         self._w_ohwi = w.permute(0, 2, 3, 1).contiguous() if (kh == 3 and kw == 3 and self.stride == 1 and self.pad == 1 and
-                                                              cin in (48, 64, 96, 192, 384)) else None
+                                                              cin in (48, 64, 96, 128, 192, 256, 384, 512)) else None
         self._images = {}
         self._device = device
 
@@ -48,6 +48,8 @@ class PackedConv(object):
         if self._w_ohwi is None:
             return None
         bn = _lib.load().pam_conv3x3_slab(int(h), int(w), self.cin, self.cout)
+        if self.cout % bn != 0:
+            return None                                  # no whole number of slabs: the generic kernel takes this layer
         img = self._images.get(bn)
         if img is None:
             cin, cout = self.cin, self.cout

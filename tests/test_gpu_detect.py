@@ -28,6 +28,10 @@ def _engine():
     (2, 26, 26, 128, 64, 1, 1, 'leaky', 'none'),
     (1, 52, 52, 32, 64, 3, 1, 'leaky', 'after'),        # Cin = 32: generic kernel
     (2, 13, 13, 512, 1024, 3, 1, 'leaky', 'after'),
+    (2, 26, 26, 256, 512, 3, 1, 'leaky', 'after'),      # 32-channel slabs
+    (2, 52, 52, 128, 256, 3, 1, 'leaky', 'after'),
+    (1, 104, 104, 64, 128, 3, 1, 'leaky', 'after'),     # wide rows: one-row tiles on a 3-wave block
+    (1, 208, 208, 64, 64, 3, 1, 'leaky', 'after'),      # rows too wide for the patch kernel -> generic kernel
     (2, 13, 13, 1024, 256, 1, 1, 'linear', 'none'),     # head conv (255 -> 256 padded below)
     (2, 30, 22, 8, 64, 3, 1, 'leaky', 'none'),          # first conv, padded 3 -> 8 / 32 -> 64
     (2, 30, 22, 64, 64, 3, 2, 'leaky', 'none'),
