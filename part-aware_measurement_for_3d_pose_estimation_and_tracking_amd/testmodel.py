@@ -75,6 +75,21 @@ def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
             t0 = time.time()
             result = model.PersonTrack_Project3DPose(frame_id=frame_id, person_bbox_list=pbl, dump_results=dump, build3D=build3D)
             dt_track = time.time() - t0
+        if result is not None and (cfg.get('VISUALIZATION') or cfg.get('SAVE_IMAGE')):      # testmodel.py:70-75 overlay
+            from pam.visualization import joints_dict, draw_points_and_skeleton
+            camera_ids, pts, person_ids = result[0], result[1], result[2]
+            for cids, poses_2d, pids in zip(camera_ids, pts, person_ids):
+                for cid, pose_2d, pid in zip(cids, poses_2d, pids):
+                    imagelist[cid] = draw_points_and_skeleton(imagelist[cid], pose_2d, joints_dict()['coco']['skeleton'],
+                                                              person_index=pid, points_color_palette='gist_rainbow',
+                                                              skeleton_color_palette='tab20', points_palette_samples=17,
+                                                              confidence_threshold=0.0)
+            if cfg.get('SAVE_IMAGE'):
+                from PIL import Image
+                store = os.path.join(cfg.OUTPUT, dataset.TEST_DATASET, 'Images')
+                os.makedirs(store, exist_ok=True)
+                for cid, im in enumerate(imagelist):
+                    Image.fromarray(np.ascontiguousarray(im[..., ::-1])).save(os.path.join(store, '%s_%d.jpg' % (frame_id, cid)))
         if on_frame is not None:
             on_frame(frame_id, timestamp, result)
         if frame_id > start + 10:

@@ -164,3 +164,18 @@ def test_evalmodel_loop_on_synthetic_dataset(tmp_path, capsys):
             np.testing.assert_allclose(res[t], e3, rtol=0, atol=1e-5)
             n += len(e3)
     assert n > 30
+
+
+def test_overlay_draws_confident_joints_only():
+    from pam.visualization import joints_dict, draw_points_and_skeleton
+    jd = joints_dict()['coco']
+    assert len(jd['keypoints']) == 17 and len(jd['skeleton']) == 19 and max(max(p) for p in jd['skeleton']) == 16
+    img = np.zeros((120, 160, 3), dtype=np.uint8)
+    pts = np.zeros((17, 3)); pts[:, 0] = np.linspace(10, 110, 17); pts[:, 1] = np.linspace(20, 140, 17); pts[:, 2] = 0.9
+    pts[16, 2] = 0.1                                                       # below threshold: not drawn
+    out = draw_points_and_skeleton(img, pts, jd['skeleton'], person_index=3, points_color_palette='gist_rainbow',
+                                   skeleton_color_palette='tab20', points_palette_samples=17, confidence_threshold=0.5)
+    assert out.shape == img.shape and out.dtype == np.uint8 and not img.any()        # input untouched
+    assert out[int(pts[0, 0]), int(pts[0, 1])].any() and out[int(pts[8, 0]), int(pts[8, 1])].any()
+    assert not out[int(pts[16, 0]) - 2:int(pts[16, 0]) + 3, int(pts[16, 1]) - 2:int(pts[16, 1]) + 3].any()
+    assert tuple(out[int(pts[0, 0]), int(pts[0, 1])]) == (0, 0, 255)               # joint 0 = first rainbow hue (red), BGR
