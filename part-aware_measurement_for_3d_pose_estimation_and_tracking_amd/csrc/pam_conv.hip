@@ -579,6 +579,7 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
             case 3841: return launch_c3<384, 1>(s, c, cfg);
             case 1284: return launch_c3<128, 4>(s, c, cfg);     // Darknet-53 widths
             case 2564: return launch_c3<256, 4>(s, c, cfg);
+            case 2563: return launch_c3<256, 3>(s, c, cfg);     // HRNet transition1: 256 -> 48 at 96 x 72
             case 2562: return launch_c3<256, 2>(s, c, cfg);
             case 5124: return launch_c3<512, 4>(s, c, cfg);
             case 5122: return launch_c3<512, 2>(s, c, cfg);

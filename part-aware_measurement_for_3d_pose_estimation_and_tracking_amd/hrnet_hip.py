@@ -229,9 +229,44 @@ class HipHRNet(ConvEngine):
                 ready[b] = self._record(b)
         if self.sync_mode == 'barrier':
             self._barrier()
-        # fuse: out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)); all terms of output i on
-        # stream i, ONE k_upsample_add per output (shift 0 for the same-resolution down terms)
+        # fuse: out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), ONE k_upsample_add per
+        # output (shift 0 for the same-resolution down terms)
         out, oready = [None] * len(mod['fuse']), [None] * len(mod['fuse'])
+        if self.sync_mode == 'barrier' and self.multi_stream:
+            # The term convolutions are small (they do not fill the chip), so the (i, j) chains are spread over the branch
+            # streams by estimated cost (longest first) instead of queueing all terms of output i on stream i; then one
+            # join, the sums on their own streams, and the join that ends the module.
+            chains = []
+            for i, row in enumerate(mod['fuse']):
+                for j, f in enumerate(row):
+                    if f is not None:
+                        ops = [f[1]] if f[0] == 'up' else list(f[1])
+                        hw, cost = xs[j].shape[2] * xs[j].shape[3], 0.0
+                        for op in ops:
+                            hw = hw // (op.stride * op.stride)
+                            cost += 8.0 + 2e-9 * xs[j].shape[0] * hw * op.cout * op.cin * op.kh * op.kw / 0.2   # us: launch + flops at ~200 TF/s
+                        chains.append((cost, i, j, f))
+            chains.sort(key=lambda c: -c[0])
+            load = [0.0] * nb
+            terms = [dict() for _ in mod['fuse']]
+            for cost, i, j, f in chains:
+                s_ = min(range(nb), key=lambda k: load[k])
+                load[s_] += cost
+                with torch.cuda.stream(self._stream(s_)):
+                    if f[0] == 'up':
+                        terms[i][j] = (self.conv(f[1], xs[j]), f[2])
+                    else:
+                        t = xs[j]
+                        for k, op in enumerate(f[1]):
+                            t = self.conv(op, t, relu=(k < len(f[1]) - 1))
+                        terms[i][j] = (t, 0)
+            self._barrier()
+            for i in range(len(mod['fuse'])):
+                with torch.cuda.stream(self._stream(i)):
+                    tl = [terms[i][j] for j in sorted(terms[i])]
+                    out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [s_ for _, s_ in tl], relu=True) if tl else torch.relu(xs[i])
+            self._barrier()
+            return out, oready
         for i, row in enumerate(mod['fuse']):
             with torch.cuda.stream(self._stream(i)):
                 terms, shifts = [], []
