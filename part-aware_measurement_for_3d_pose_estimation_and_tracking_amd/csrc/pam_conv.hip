@@ -43,6 +43,7 @@ constexpr int KC = 64;               // K elements staged per LDS chunk (two 32-
 constexpr int ROWB = KC * 2 + 16;    // LDS row pitch in bytes: 128 B of data + 16 B pad (spreads ds_read_b128 over banks)
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define OOB_OFFSET 0x80000000u          // beyond any buffer's num_records: the hardware bounds check returns zeros
 
 // Block tile: BM = 64*WM output pixels x BN = 16*NTW*WN output channels; each wave owns 64 pixels x 16*NTW channels
@@ -280,6 +281,42 @@ __device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((flo
 
 // the deep small-image layers run one workgroup per CU (one wave per SIMD): give those instantiations the whole register
 // file, otherwise the scheduler, starved by the chunk-prefetch registers, reads each MFMA fragment right before its use
+// One lane's row piece of 4*NTW contiguous bf16 channels (8*NTW bytes at byte offset o, 8-byte aligned; 16-byte aligned
+// when NTW is even or the lane group g is even) as 16-byte accesses where possible.  NTW = 3 (24 bytes) splits 16 + 8 for
+// even g and 8 + 16 for odd g, so the 16-byte half is always aligned.
+template <int NTW>
+__device__ __forceinline__ void c3_row_load(__amdgpu_buffer_rsrc_t rs, unsigned o, int g, uint32_t* d) {
+    if constexpr (NTW == 1) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, o, 0, 0); d[0] = v[0]; d[1] = v[1];
+    } else if constexpr (NTW == 2) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    } else if constexpr (NTW == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0), w = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16, 0, 0);
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; d[4] = w[0]; d[5] = w[1]; d[6] = w[2]; d[7] = w[3];
+    } else {
+        static_assert(NTW == 3, "slab width");
+        const bool odd = g & 1;
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, o + (odd ? 8u : 0u), 0, 0);
+        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs, o + (odd ? 0u : 16u), 0, 0);
+        d[0] = odd ? h[0] : q[0]; d[1] = odd ? h[1] : q[1]; d[2] = odd ? q[0] : q[2];
+        d[3] = odd ? q[1] : q[3]; d[4] = odd ? q[2] : h[0]; d[5] = odd ? q[3] : h[1];
+    }
+}
+template <int NTW>
+__device__ __forceinline__ void c3_row_store(uint16_t* p, int g, const uint32_t* d) {
+    if constexpr (NTW == 1) {
+        *(u32x2*)p = (u32x2){d[0], d[1]};
+    } else if constexpr (NTW == 2) {
+        *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]};
+    } else if constexpr (NTW == 4) {
+        *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]}; *(u32x4*)(p + 8) = (u32x4){d[4], d[5], d[6], d[7]};
+    } else {
+        const bool odd = g & 1;
+        *(u32x4*)(p + (odd ? 4 : 0)) = odd ? (u32x4){d[2], d[3], d[4], d[5]} : (u32x4){d[0], d[1], d[2], d[3]};
+        *(u32x2*)(p + (odd ? 0 : 8)) = odd ? (u32x2){d[0], d[1]} : (u32x2){d[4], d[5]};
+    }
+}
+
 template <int CIN, int NTW, int MT, int NWAVES, int PMAX>
 __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_conv3x3(C3Args a) {
     constexpr int T = 64 * NWAVES, BN = 16 * NTW;
@@ -307,8 +344,7 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * CIN * 2), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wimg, 0, (int)((size_t)(a.Cout / BN) * NCHUNK * WIMG), 0x00020000);
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
-    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-    u32x2 rres[MT][NTW];
+    uint32_t rres[MT][2 * NTW];                         // residual row piece of this lane: 4*NTW contiguous channels
     char* zero_slot = Wsm + WIMG;                       // 64 zero bytes: K-tail A lanes (CIN = 48) + slack behind the last weight row
     if (tid < 4) *(u32x4*)(zero_slot + tid * 16) = (u32x4){0, 0, 0, 0};
 
@@ -386,9 +422,8 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
                 const int p = wave * 16 * MT + i * 16 + (lane & 15);
                 const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
                 const bool ok = p < nslots && px < a.W;
-                const unsigned o = ok ? (unsigned)(((((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4) * 2) : OOB_OFFSET;
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) rres[i][j] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, o, ok ? j * 32 : 0, 0);
+                const unsigned o = ok ? (unsigned)(((((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4 * NTW) * 2) : OOB_OFFSET;
+                c3_row_load<NTW>(rs_res, o, g, rres[i]);
             }
         }
         if (a.dbg & 2) continue;
@@ -435,39 +470,40 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     }
 
     // ---- epilogue straight from the accumulators.  With the weights as the MFMA A operand the D tile has channels on
-    // its rows: this lane holds channels n0 + j*16 + g*4 .. +3 of pixel slot i*16 + (lane & 15) -> one 8-byte residual load
-    // and one 8-byte store per (i, j); the 4 lane groups of a pixel cover 32 contiguous bytes.
+    // its rows, and the host packs the slab's weight rows so that row j*16 + 4g + r is channel n0 + 4*NTW*g + 4j + r: this
+    // lane then holds 4*NTW CONTIGUOUS channels of pixel slot i*16 + (lane & 15) -> residual loads and stores are 16 bytes
+    // wide (the store tail is issue-bound), and the 4 lane groups of a pixel cover the slab's 32*NTW contiguous bytes.
     C3_STAMP(60);
     if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)acc[0][0][0]; return; }
-    typedef __attribute__((ext_vector_type(4))) short bf16x4;
     f32x4 bias4[NTW];
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + j * 16 + g * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int p = wave * 16 * MT + i * 16 + (lane & 15);
         const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
         if (p < nslots && px < a.W) {
-            const size_t o = (((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4;
+            uint32_t ov[2 * NTW];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                const bf16x4 rr = __builtin_bit_cast(bf16x4, rres[i][j]);
                 float v[4];
+                const float r0 = bf16_to_f32((uint16_t)(rres[i][2 * j] & 0xffffu)), r1 = bf16_to_f32((uint16_t)(rres[i][2 * j] >> 16));
+                const float r2 = bf16_to_f32((uint16_t)(rres[i][2 * j + 1] & 0xffffu)), r3 = bf16_to_f32((uint16_t)(rres[i][2 * j + 1] >> 16));
+                const float rr[4] = {r0, r1, r2, r3};
                 if constexpr (!c3_general_act(CIN)) {   // HRNet-only widths: codes 0 / 1, minimal epilogue
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[r] = acc[i][j][r] + bias4[j][r];
-                        if (a.res) v[r] += bf16_to_f32((uint16_t)rr[r]);
+                        if (a.res) v[r] += rr[r];
                         if (a.relu) v[r] = fmaxf(v[r], 0.0f);
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = epi_act(acc[i][j][r] + bias4[j][r], a.res ? bf16_to_f32((uint16_t)rr[r]) : 0.0f, a.relu);
+                    for (int r = 0; r < 4; ++r) v[r] = epi_act(acc[i][j][r] + bias4[j][r], a.res ? rr[r] : 0.0f, a.relu);
                 }
-                u32x2 ov = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)(a.out + o + j * 16) = ov;
+                ov[2 * j] = pack_bf16x2(v[0], v[1]); ov[2 * j + 1] = pack_bf16x2(v[2], v[3]);
             }
+            c3_row_store<NTW>(a.out + (((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4 * NTW, g, ov);
         }
     }
     C3_STAMP(61);
@@ -528,6 +564,76 @@ extern "C" int pam_conv3x3_slab(int H, int W, int Cin, int Cout) {
     return H * W <= 128 ? 16 : (H * W <= 512 ? 32 : 48);
 }
 
+// ====================================================================================================================
+// k_conv_stem: the first convolution of both networks' stems -- 3x3 / stride 2 / pad 1 from the 8-channel (RGB + zeros) input
+// to 64 channels.  K per tap ROW is 3 taps x 8 channels = 24 <= 32, so one v_mfma_f32_16x16x32_bf16 covers a whole tap row:
+// lane (pixel l & 15, k-group g = l >> 4) supplies as its B fragment the 16-byte input pixel (2y + ky - 1, 2x + g - 1)
+// straight from global memory (g = 3 and the zero padding come from the buffer bounds check), 3 loads and 12 MFMAs per
+// 16 output pixels x 64 channels.  The weights (A operand, 12 fragments) live in registers for the wave's whole row; their
+// rows are permuted like k_conv3x3's so a lane ends with 16 contiguous channels: each pixel's 128 output bytes are written
+// by 4 lanes x 2 x 16 B.  Pure streaming: ~35 MB in, ~71 MB out at 20 crops.  One wave per output row.
+// ====================================================================================================================
+struct StemArgs { const uint16_t* in; const uint16_t* wfrag; const float* bias; uint16_t* out; int N, H, W, Ho, Wo, relu; };
+__global__ __launch_bounds__(256) void k_conv_stem(StemArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row_id = blockIdx.x * 4 + wave;
+    if (row_id >= a.N * a.Ho) return;
+    const int n = row_id / a.Ho, oy = row_id - n * a.Ho;
+    const int px = lane & 15, g = lane >> 4;
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * 16), 0x00020000);
+    bf16x8 wf[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) wf[j][ky] = *(const bf16x8*)(a.wfrag + ((size_t)(j * 3 + ky) * 64 + lane) * 8);
+    f32x4 bias4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + g * 16 + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned rowoff[3];                                  // byte offset of input row 2*oy + ky - 1, or OOB
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        rowoff[ky] = (iy >= 0 && iy < a.H && g < 3) ? (unsigned)((((size_t)n * a.H + iy) * a.W) * 16) : OOB_OFFSET;
+    }
+    const int ntiles = (a.Wo + 15) >> 4;
+    auto load_tile = [&](int t, bf16x8* b) {
+        const int ix = 2 * (t * 16 + px) + g - 1;
+        const bool ok = ix >= 0 && ix < a.W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+            b[ky] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (ok && rowoff[ky] != OOB_OFFSET) ? rowoff[ky] + (unsigned)ix * 16u : OOB_OFFSET, 0, 0));
+    };
+    bf16x8 cur[3], nxt[3];
+    load_tile(0, cur);
+    uint16_t* orow = a.out + (((size_t)n * a.Ho + oy) * a.Wo) * 64 + g * 16;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) load_tile(t + 1, nxt);
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = bias4[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j][ky]), __builtin_bit_cast(bf16x8_t, cur[ky]), acc[j], 0, 0, 0);
+        const int ox = t * 16 + px;
+        if (ox < a.Wo) {
+            uint32_t d[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = epi_act1(acc[j][r], a.relu & 3);
+                d[2 * j] = pack_bf16x2(v[0], v[1]); d[2 * j + 1] = pack_bf16x2(v[2], v[3]);
+            }
+            *(u32x4*)(orow + (size_t)ox * 64) = (u32x4){d[0], d[1], d[2], d[3]};
+            *(u32x4*)(orow + (size_t)ox * 64 + 8) = (u32x4){d[4], d[5], d[6], d[7]};
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) cur[ky] = nxt[ky];
+    }
+}
+
 extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                                     const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
                                     int KH, int KW, int stride, int pad, int relu, int tile_cfg) {
@@ -541,6 +647,13 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.Ktot = KH * KW * Cin; a.Kpad = (a.Ktot + KC - 1) / KC * KC; a.M = N * a.Ho * a.Wo;
     if (H >= 32768 || W >= 32768) return PAM_E_ARG;
+    if (w_img && Cin == 8 && Cout == 64 && KH == 3 && KW == 3 && stride == 2 && pad == 1 && !residual && tile_cfg < 0) {
+        StemArgs t;                                      // w_img = the 12 pre-permuted A fragments (see pam.h)
+        t.in = a.in; t.wfrag = (const uint16_t*)w_img; t.bias = bias; t.out = a.out;
+        t.N = N; t.H = H; t.W = W; t.Ho = a.Ho; t.Wo = a.Wo; t.relu = relu;
+        hipLaunchKernelGGL(k_conv_stem, dim3((N * a.Ho + 3) / 4), dim3(256), 0, (hipStream_t)stream, t);
+        return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+    }
     if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&
         (Cin == 48 || Cin == 64 || Cin == 96 || Cin == 192 || Cin == 384 || Cin == 128 || Cin == 256 || Cin == 512)) {
         const int ntw = pam_conv3x3_slab(H, W, Cin, Cout) / 16;

@@ -42,9 +42,24 @@ class PackedConv(object):
                                                               cin in (48, 64, 96, 128, 192, 256, 384, 512)) else None
         self._images = {}
         self._device = device
+        # stem convolution (8 -> 64 channels, 3x3 stride 2): the 12 MFMA A fragments of k_conv_stem, [n-tile j][ky][lane][8]:
+        # lane l holds, for output channel 16*((l & 15) >> 2) + 4*j + (l & 3), the 8 input channels of tap (ky, kx = l >> 4)
+        self._stem = None
+        if cin == 8 and cout == 64 and kh == 3 and kw == 3 and self.stride == 2 and self.pad == 1:
+            lanes = torch.arange(64)
+            q, kx = lanes & 15, lanes >> 4
+            frag = torch.zeros((4, 3, 64, 8), dtype=torch.float32)
+            for j in range(4):
+                ch = 16 * (q >> 2) + 4 * j + (q & 3)
+                for ky in range(3):
+                    sel = kx < 3
+                    frag[j, ky, sel] = w[ch[sel], :, ky, kx[sel]]
+            self._stem = frag.to(torch.bfloat16).to(device).contiguous()
 
     def image(self, h, w):
         """Weight image [cout/BN][cin/CK][BN][pitch/2] bf16 (row = 9 taps x CK channels + pad) for this layer at input h x w."""
+        if self._stem is not None:
+            return self._stem
         if self._w_ohwi is None:
             return None
         bn = _lib.load().pam_conv3x3_slab(int(h), int(w), self.cin, self.cout)
@@ -56,6 +71,10 @@ class PackedConv(object):
             ck = 48 if cin == 48 else (64 if cin >= 192 else 32)
             pitch = {48: 864, 32: 608, 64: 1184}[ck] // 2
             w5 = self._w_ohwi.reshape(cout // bn, bn, 9, cin // ck, ck)                  # [slab][co][tap][chunk][c]
+            # row j*16 + q of a slab holds channel 4*ntw*(q >> 2) + 4*j + (q & 3): with the weights as the MFMA A operand a
+            # lane's accumulators are then 4*ntw contiguous output channels (16-byte epilogue accesses, see k_conv3x3)
+            ntw = bn // 16
+            w5 = w5[:, [4 * ntw * (q >> 2) + 4 * j + (q & 3) for j in range(ntw) for q in range(16)]]
             t = torch.zeros((cout // bn, cin // ck, bn, pitch), dtype=torch.float32)
             t[:, :, :, :9 * ck] = w5.permute(0, 3, 1, 2, 4).reshape(cout // bn, cin // ck, bn, 9 * ck)
             img = t.to(torch.bfloat16).to(self._device).contiguous()
@@ -215,6 +234,39 @@ class HipHRNet(ConvEngine):
         """xs[b]: tensor or ('lazy', op, src_tensor, src_event) for a branch created by a transition; ready[b]: event."""
         nb = len(mod['branches'])
         xs, ready = list(xs), list(ready)
+        fuse = mod['fuse']
+        if self.sync_mode == 'barrier' and self.multi_stream:
+            # Cross-stream joins cost ~10 us of idle chip each, so a module has exactly one: stream b runs branch b AND the
+            # fuse chains that start from branch b's output (strided-conv chains down, 1x1 convs up); after the join, the
+            # sum of output i runs on stream i, where branch i of the next module continues without any further sync.
+            terms = [dict() for _ in fuse]
+            for b, blocks in enumerate(mod['branches']):
+                with torch.cuda.stream(self._stream(b)):
+                    x = xs[b]
+                    if isinstance(x, tuple):                          # transition conv runs on the new branch's own stream
+                        x = self.conv(x[1], x[2], relu=True)
+                    for c1, c2 in blocks:
+                        y = self.conv(c1, x, relu=True)
+                        x = self.conv(c2, y, res=x, relu=True)
+                    xs[b] = x
+                    for i, row in enumerate(fuse):
+                        f = row[b] if b < len(row) else None
+                        if f is None:
+                            continue
+                        if f[0] == 'up':
+                            terms[i][b] = (self.conv(f[1], x), f[2])
+                        else:
+                            t = x
+                            for k, op in enumerate(f[1]):
+                                t = self.conv(op, t, relu=(k < len(f[1]) - 1))
+                            terms[i][b] = (t, 0)
+            self._barrier()
+            out = [None] * len(fuse)
+            for i in range(len(fuse)):
+                with torch.cuda.stream(self._stream(i)):
+                    tl = [terms[i][j] for j in sorted(terms[i])]
+                    out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])
+            return out, [None] * len(fuse)
         for b, blocks in enumerate(mod['branches']):
             with torch.cuda.stream(self._stream(b)):
                 x = xs[b]
@@ -227,47 +279,10 @@ class HipHRNet(ConvEngine):
                     x = self.conv(c2, y, res=x, relu=True)
                 xs[b] = x
                 ready[b] = self._record(b)
-        if self.sync_mode == 'barrier':
-            self._barrier()
-        # fuse: out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), ONE k_upsample_add per
-        # output (shift 0 for the same-resolution down terms)
-        out, oready = [None] * len(mod['fuse']), [None] * len(mod['fuse'])
-        if self.sync_mode == 'barrier' and self.multi_stream:
-            # The term convolutions are small (they do not fill the chip), so the (i, j) chains are spread over the branch
-            # streams by estimated cost (longest first) instead of queueing all terms of output i on stream i; then one
-            # join, the sums on their own streams, and the join that ends the module.
-            chains = []
-            for i, row in enumerate(mod['fuse']):
-                for j, f in enumerate(row):
-                    if f is not None:
-                        ops = [f[1]] if f[0] == 'up' else list(f[1])
-                        hw, cost = xs[j].shape[2] * xs[j].shape[3], 0.0
-                        for op in ops:
-                            hw = hw // (op.stride * op.stride)
-                            cost += 8.0 + 2e-9 * xs[j].shape[0] * hw * op.cout * op.cin * op.kh * op.kw / 0.2   # us: launch + flops at ~200 TF/s
-                        chains.append((cost, i, j, f))
-            chains.sort(key=lambda c: -c[0])
-            load = [0.0] * nb
-            terms = [dict() for _ in mod['fuse']]
-            for cost, i, j, f in chains:
-                s_ = min(range(nb), key=lambda k: load[k])
-                load[s_] += cost
-                with torch.cuda.stream(self._stream(s_)):
-                    if f[0] == 'up':
-                        terms[i][j] = (self.conv(f[1], xs[j]), f[2])
-                    else:
-                        t = xs[j]
-                        for k, op in enumerate(f[1]):
-                            t = self.conv(op, t, relu=(k < len(f[1]) - 1))
-                        terms[i][j] = (t, 0)
-            self._barrier()
-            for i in range(len(mod['fuse'])):
-                with torch.cuda.stream(self._stream(i)):
-                    tl = [terms[i][j] for j in sorted(terms[i])]
-                    out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [s_ for _, s_ in tl], relu=True) if tl else torch.relu(xs[i])
-            self._barrier()
-            return out, oready
-        for i, row in enumerate(mod['fuse']):
+        # fuse: out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)); all terms of output i on
+        # stream i, ONE k_upsample_add per output (shift 0 for the same-resolution down terms)
+        out, oready = [None] * len(fuse), [None] * len(fuse)
+        for i, row in enumerate(fuse):
             with torch.cuda.stream(self._stream(i)):
                 terms, shifts = [], []
                 for j, f in enumerate(row):
@@ -283,8 +298,6 @@ class HipHRNet(ConvEngine):
                         terms.append(t); shifts.append(0)
                 out[i] = self.upsample_add(xs[i], terms, shifts, relu=True) if terms else torch.relu(xs[i])
                 oready[i] = self._record(i)
-        if self.sync_mode == 'barrier':
-            self._barrier()
         return out, oready
 
     def features(self, x8):
@@ -321,9 +334,13 @@ class HipHRNet(ConvEngine):
         ready = [ev, ev]
         for m in self.stage2:
             xs, ready = self._hr_module(m, xs, ready)
+        if self.sync_mode == 'barrier':
+            self._barrier()                                           # the new branch's stream reads the last sum of stage 2
         xs = xs + [('lazy', self.t2, xs[-1], ready[-1])]; ready = ready + [ready[-1]]
         for m in self.stage3:
             xs, ready = self._hr_module(m, xs, ready)
+        if self.sync_mode == 'barrier':
+            self._barrier()
         xs = xs + [('lazy', self.t3, xs[-1], ready[-1])]; ready = ready + [ready[-1]]
         for m in self.stage4:
             xs, ready = self._hr_module(m, xs, ready)
