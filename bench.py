@@ -87,35 +87,45 @@ def main():
     cams = [Camera(j, P32[j], K32[j], RT32[j], Fm[j], w=fw, h=fh) for j in range(C)]
     max_dets = 8
     pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
-                         rank=rank, use_graph=not args.no_graph)
-    mine = pipe.mine
-    kl = len(mine)
+                         rank=rank, use_graph=not args.no_graph, shard='crops')
+    from pam.distributed import CropGather
 
-    # ---- inputs resident in HBM ----------------------------------------------------------------------------------------
-    g = torch.Generator().manual_seed(1234 + rank)
-    frames_dev = [torch.randint(0, 256, (fh, fw, 3), dtype=torch.uint8, generator=g).to(dev) for _ in mine]
-    frame_ptrs = torch.tensor([f.data_ptr() for f in frames_dev] or [0], dtype=torch.int64, device=dev)
+    # ---- inputs resident in HBM.  The frame's crops (ordered by view, then person) are dealt out evenly over the ranks; every
+    # rank holds the (synthetic) frames of all views, its share of the boxes, and the synthetic keypoints of ITS crops only.
+    g = torch.Generator().manual_seed(1234)
+    frames_dev = [torch.randint(0, 256, (fh, fw, 3), dtype=torch.uint8, generator=g).to(dev) for _ in range(C)]
+    frame_ptrs = torch.tensor([f.data_ptr() for f in frames_dev], dtype=torch.int64, device=dev)
     n_det_all, det_all = synth.pack_frames(seq['frames'], max_dets)            # (F,C), (F,C,maxd,17,3) (y,x,s)
-    per_frame = []
+    per_frame, crops_per_frame, local_crops, parts_seen = [], [], [], None
     for t in range(nF):
         vl, sl, bx = [], [], []
-        for li, v in enumerate(mine):
+        for v in range(C):
             for s, kp in enumerate(seq['frames'][t][v]):
                 x0, y0, x1, y1 = kp[:, 0].min(), kp[:, 1].min(), kp[:, 0].max(), kp[:, 1].max()
-                vl.append(li); sl.append(s)
+                vl.append(v); sl.append(s)
                 bx.append([x0 - 0.125 * (x1 - x0), y0 - 0.125 * (y1 - y0), 1.25 * (x1 - x0), 1.25 * (y1 - y0)])
-        per_frame.append((torch.tensor(vl, dtype=torch.int32, device=dev), torch.tensor(sl, dtype=torch.int32, device=dev),
-                          torch.tensor(bx, dtype=torch.float32, device=dev).reshape(-1, 4),
-                          torch.tensor(n_det_all[t, mine], dtype=torch.int32, device=dev),
-                          torch.tensor(det_all[t][mine], dtype=torch.float64, device=dev).reshape(kl, max_dets, 17, 3)))
-    crops_per_frame = [int(sum(len(seq['frames'][t][v]) for v in range(C))) for t in range(nF)]
-    local_crops = [int(p[0].numel()) for p in per_frame]
+        select, parts = CropGather.select_index(vl, sl, C, max_dets, world)
+        a, b = parts[rank]
+        mine_rows = np.full((C, max_dets, 17, 3), np.nan)                       # other ranks' rows must come through the exchange
+        for i in range(a, b):
+            mine_rows[vl[i], sl[i]] = det_all[t][vl[i], sl[i]]
+        if world == 1:
+            mine_rows = det_all[t]
+        per_frame.append((torch.tensor(vl[a:b], dtype=torch.int32, device=dev), torch.tensor(sl[a:b], dtype=torch.int32, device=dev),
+                          torch.tensor(bx[a:b], dtype=torch.float32, device=dev).reshape(-1, 4),
+                          torch.tensor(n_det_all[t], dtype=torch.int32, device=dev),
+                          torch.tensor(mine_rows, dtype=torch.float64, device=dev),
+                          torch.tensor(select, dtype=torch.int64, device=dev)))
+        crops_per_frame.append(len(vl)); local_crops.append(b - a)
+        if len(vl) == int(np.median(crops_per_frame)):
+            parts_seen = [q - p for p, q in parts]
     torch.cuda.synchronize()
 
     def step(t, ev=None):
-        vl, sl, bx, nd, dd = per_frame[t]
-        pipe.pose_step(frame_ptrs, vl, sl, bx, ev)
-        pipe.track_step(t, nd, dd)
+        vl, sl, bx, nd, dd, sel = per_frame[t]
+        pipe.pose_step_crops(frame_ptrs, vl, sl, bx, ev)
+        pipe.crop_gather.send.copy_(dd)          # the tracker consumes the seeded synthetic keypoints, not the random net's
+        pipe.track_step_crops(t, nd, sel)
 
     # ---- warm-up (includes hipGraph capture of every crop count that occurs) -------------------------------------------
     for n in sorted(set(local_crops)):
@@ -178,7 +188,7 @@ def main():
             'dtype': 'bf16 convs / f64 matching', 'data': 'synthetic',
             'config': {'workload': '%s-like %s: %d cams %dx%d, %d persons, %d crops/frame 384x288, 17 joints'
                                    % ({'S1': 'Campus', 'S2': 'Shelf', 'S3': 'Panoptic-5', 'S4': 'Panoptic-31'}[size], size, C, fw, fh, P, int(np.median(crops_per_frame))),
-                       'views_per_rank': [len(p) for p in pipe.gather.parts], 'tracker': 'fused HIP frame kernel (f64)',
+                       'crops_per_rank': parts_seen, 'sharding': 'crops dealt evenly over ranks', 'tracker': 'fused HIP frame kernel (f64)',
                        'hrnet_weights': pipe.net.weights if pipe.net else None, 'conv_backend': pipe.net.backend if pipe.net else None, 'exchange': 'all_gather per frame' if world > 1 else 'none'},
             'roofline': {'kernel': 'HRNet-W48 conv stack: k_conv3x3 / k_conv_igemm / k_upsample_add (hipGraph replay, %d crops, %d launches)'
                                    % (n_med, work[n_med]['launches'] if n_med in work else 0),
@@ -201,7 +211,7 @@ def main():
             b.record(); torch.cuda.synchronize()
             return a.elapsed_time(b) / iters * 1e-3
         tq = W + K - 1
-        vl, sl, bx, nd, dd = per_frame[tq]
+        vl, sl, bx, nd, dd, sel = per_frame[tq]
         n = int(vl.numel())
         kern = []
         if n > 0 and pipe.net is not None:
@@ -211,7 +221,7 @@ def main():
             kern.append({'kernel': 'k_preprocess_crops', 'bound': 'hbm', 'achieved': by / s / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': by / s / 1e9 / HBM_PEAK_GBS, 'us': s * 1e6, 'bytes': by})
             hm = pipe.net.heatmaps(x)
-            s = ev_time(lambda: pipe.net.decode(hm, vl, sl, bx, pipe.det_local))
+            s = ev_time(lambda: pipe.net.decode(hm, vl, sl, bx, pipe.crop_gather.send))
             by = n * (17 * 96 * 72 * 4 + 17 * 3 * 8)
             kern.append({'kernel': 'k_decode_nhwc', 'bound': 'hbm', 'achieved': by / s / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': by / s / 1e9 / HBM_PEAK_GBS, 'us': s * 1e6, 'bytes': by})

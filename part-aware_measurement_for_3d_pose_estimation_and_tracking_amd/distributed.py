@@ -1,5 +1,9 @@
-"""Multi-GPU: camera views are partitioned over ranks (one process per GPU); the only exchange is ONE all-gather per
-frame of the per-view 2D keypoint records (RCCL over xGMI when the backend is 'nccl'; 'gloo' in the CPU tests).
+"""Multi-GPU: the per-view / per-crop work is partitioned over ranks (one process per GPU); the only exchange is ONE
+all-gather per frame of the 2D keypoint records (RCCL over xGMI when the backend is 'nccl'; 'gloo' in the CPU tests).
+
+Two partitions: ``ViewGather`` -- whole camera views per rank (the natural split when every rank ingests its own cameras;
+SURVEY 8e), and ``CropGather`` -- the frame's person crops dealt out evenly regardless of view (HRNet time is proportional
+to crops, and 5 views never divide evenly over 2 / 4 / 8 ranks); ``FramePipeline(shard='crops')`` uses the latter.
 
 Per-view work (crop, HRNet, decode) is sharded; the cross-view step (association, part-aware filter, DLT, tracker) is
 replicated: after the gather every rank runs the identical deterministic frame kernel, so no broadcast of results is
@@ -50,3 +54,43 @@ class ViewGather(object):
         self.n_det.copy_(full[:, 0].to(torch.int32))
         self.det.copy_(full[:, 1:].reshape(self.C, self.max_dets, NUM_JOINTS, 3))
         return self.n_det, self.det
+
+
+def crop_partition(n_crops, world):
+    """rank r owns the contiguous crop range [r*n // world, (r+1)*n // world) (sizes differ by at most one)."""
+    return [(r * n_crops // world, (r + 1) * n_crops // world) for r in range(world)]
+
+
+class CropGather(object):
+    """Every rank decodes ITS crops into a full-shape (C, max_dets, 17, 3) float64 buffer (``self.send``; rows of other
+    ranks' crops are don't-care), the buffers are all-gathered, and row (view, slot) is taken from the rank that owns
+    that crop (``select_index``).  Identical result on every rank."""
+
+    def __init__(self, n_views, max_dets, world, rank, device, group=None):
+        self.C, self.max_dets, self.world, self.rank, self.group = n_views, max_dets, world, rank, group
+        self.rows = n_views * max_dets
+        self.send = torch.zeros((n_views, max_dets, NUM_JOINTS, 3), dtype=torch.float64, device=device)
+        self.recv = torch.zeros((world, self.rows, NUM_JOINTS * 3), dtype=torch.float64, device=device)
+        self.det = torch.zeros((n_views, max_dets, NUM_JOINTS, 3), dtype=torch.float64, device=device)
+
+    @staticmethod
+    def select_index(view_of, slot_of, n_views, max_dets, world):
+        """Host helper: the frame's crop list (view, slot per crop; the order defines the partition) -> (select, parts):
+        select[(view, slot)] = row of the all-gathered buffer that holds that crop (int64, C*max_dets), parts = per-rank
+        crop ranges.  Empty slots point at rank 0's (unused) row."""
+        import numpy as np
+        parts = crop_partition(len(view_of), world)
+        rows = n_views * max_dets
+        owner = np.zeros(rows, dtype=np.int64)
+        for r, (a, b) in enumerate(parts):
+            for i in range(a, b):
+                owner[int(view_of[i]) * max_dets + int(slot_of[i])] = r
+        return owner * rows + np.arange(rows, dtype=np.int64), parts
+
+    def gather(self, select):
+        """select: (C*max_dets,) int64 device tensor from select_index -> det (C, max_dets, 17, 3) float64, all ranks alike."""
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
+            torch.index_select(self.recv.view(self.world * self.rows, -1), 0, select, out=self.det.view(self.rows, -1))
+            return self.det
+        return self.send

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .distributed import ViewGather, view_partition
+from .distributed import CropGather, ViewGather, view_partition
 from .hrnet import HRNetPose
 
 NUM_JOINTS = 17
@@ -16,7 +16,9 @@ NUM_JOINTS = 17
 
 class FramePipeline(object):
     def __init__(self, calib_cameras, matcher, conf_threshold, frame_hw, max_dets=8, max_tracks=16, device=0, world=1,
-                 rank=0, group=None, use_graph=True, hrnet=True, seed=0):
+                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views'):
+        """shard: 'views' -- rank owns whole camera views (pose_step / track_step take view-local inputs); 'crops' -- the
+        frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices)."""
         self.device = torch.device('cuda:%d' % device)
         torch.cuda.set_device(self.device)
         self.cams = calib_cameras
@@ -30,7 +32,9 @@ class FramePipeline(object):
                                 np.stack([c.RK_INV for c in calib_cameras]), np.stack([c.position for c in calib_cameras]))
         self.net = HRNetPose(48, 17, None, resolution=(384, 288), device=device, use_graph=use_graph, seed=seed,
                              max_dets=max_dets) if hrnet else None
+        self.shard = shard
         self.gather = ViewGather(self.C, max_dets, world, rank, self.device, group)
+        self.crop_gather = CropGather(self.C, max_dets, world, rank, self.device, group) if shard == 'crops' else None
         self.mine = self.gather.mine
         # decode target: this rank's views only, (len(mine), max_dets, 17, 3)
         self.det_local = torch.zeros((max(1, len(self.mine)), max_dets, NUM_JOINTS, 3), dtype=torch.float64, device=self.device)
@@ -59,6 +63,31 @@ class FramePipeline(object):
     def track_step(self, frame_id, n_det_local, det_local, fetch=True):
         """Exchange (if sharded) + fused tracker kernel on the gathered keypoints; async fetch of the record."""
         n_det, det = self.gather.gather(n_det_local, det_local)
+        st = self.stream_ptr()
+        self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
+        if fetch:
+            self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
+
+    # -- crop-balanced sharding ----------------------------------------------------------------------------------------------
+    def pose_step_crops(self, frame_ptrs, view_of, slot_of, boxes, time_events=None):
+        """HRNet side for this rank's share of the frame's crops; view_of indexes ALL views (frame_ptrs has C entries).
+        Decodes straight into the exchange buffer at (view, slot)."""
+        n = int(view_of.numel())
+        if n == 0 or self.net is None:
+            return
+        x = self.net.input_buffer(n)
+        self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, view_of, boxes, x)
+        if time_events is not None:
+            time_events[0].record()
+        hm = self.net.heatmaps(x)
+        if time_events is not None:
+            time_events[1].record()
+        self.net.decode(hm, view_of, slot_of, boxes, self.crop_gather.send)
+
+    def track_step_crops(self, frame_id, n_det, select, fetch=True):
+        """n_det (C,) int32 and select (CropGather.select_index) are the same on every rank (they follow from the frame's box
+        list); the keypoint rows come from ``crop_gather.send`` of the rank that owns each crop."""
+        det = self.crop_gather.gather(select)
         st = self.stream_ptr()
         self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
         if fetch:

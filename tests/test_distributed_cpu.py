@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import pam
-from pam.distributed import ViewGather, view_partition
+from pam.distributed import CropGather, ViewGather, crop_partition, view_partition
 
 
 def test_view_partition():
@@ -53,3 +53,45 @@ def test_all_gather_world2_gloo():
         port = _free_port()
         mp.spawn(_worker, args=(2, port, C, 4, ret), nprocs=2, join=True)
         assert ret[0] and ret[1]
+
+
+def test_crop_partition_is_balanced_and_contiguous():
+    for n in (0, 1, 7, 20, 217):
+        for W in (1, 2, 4, 8):
+            parts = crop_partition(n, W)
+            assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+    assert [b - a for a, b in crop_partition(20, 8)] == [2, 3, 2, 3, 2, 3, 2, 3]
+
+
+def _crop_worker(rank, world, port, C, max_dets, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = np.random.default_rng(1)                       # same stream on all ranks = the "global" truth
+    g = CropGather(C, max_dets, world, rank, torch.device('cpu'))
+    ok = True
+    for t in range(3):
+        n_det = rng.integers(0, max_dets + 1, size=C)
+        det = rng.normal(size=(C, max_dets, 17, 3))
+        view_of = [v for v in range(C) for _ in range(n_det[v])]
+        slot_of = [s for v in range(C) for s in range(n_det[v])]
+        select, parts = CropGather.select_index(view_of, slot_of, C, max_dets, world)
+        a, b = parts[rank]
+        g.send.fill_(float(100 + rank))                  # rows this rank does not own hold garbage
+        for i in range(a, b):
+            g.send[view_of[i], slot_of[i]] = torch.tensor(det[view_of[i], slot_of[i]])
+        out = g.gather(torch.tensor(select)).numpy()
+        for v in range(C):
+            ok &= bool(np.array_equal(out[v, :n_det[v]], det[v, :n_det[v]]))
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_crop_gather_world2_gloo():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_crop_worker, args=(2, _free_port(), 5, 4, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
