@@ -45,6 +45,7 @@ def main():
     ap.add_argument('--no-batched', action='store_true')
     ap.add_argument('--batched-scenes', type=int, default=2048)
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-overlap', action='store_true', help='run the tracker of frame t on the pose stream instead of under frame t+1')
     args = ap.parse_args()
 
     import torch
@@ -87,7 +88,7 @@ def main():
     cams = [Camera(j, P32[j], K32[j], RT32[j], Fm[j], w=fw, h=fh) for j in range(C)]
     max_dets = 8
     pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
-                         rank=rank, use_graph=not args.no_graph, shard='crops')
+                         rank=rank, use_graph=not args.no_graph, shard='crops', overlap_tracker=not args.no_overlap)
     from pam.distributed import CropGather
 
     # ---- inputs resident in HBM.  The frame's crops (ordered by view, then person) are dealt out evenly over the ranks; every

@@ -16,9 +16,11 @@ NUM_JOINTS = 17
 
 class FramePipeline(object):
     def __init__(self, calib_cameras, matcher, conf_threshold, frame_hw, max_dets=8, max_tracks=16, device=0, world=1,
-                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views'):
+                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False):
         """shard: 'views' -- rank owns whole camera views (pose_step / track_step take view-local inputs); 'crops' -- the
-        frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices)."""
+        frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices).
+        overlap_tracker (crops mode): exchange + tracker kernel + fetch of frame t run on their own stream, under the conv
+        stack of frame t+1 (the tracker is one workgroup per scene; it rides on CUs the conv kernels leave idle)."""
         self.device = torch.device('cuda:%d' % device)
         torch.cuda.set_device(self.device)
         self.cams = calib_cameras
@@ -42,6 +44,8 @@ class FramePipeline(object):
         self.out_i = torch.zeros((1, L.int_words), dtype=torch.int32).pin_memory()
         self.out_d = torch.zeros((1, L.dbl_words), dtype=torch.float64).pin_memory()
         self.ev = None
+        self.track_stream = torch.cuda.Stream(self.device) if (overlap_tracker and shard == 'crops') else None
+        self.ev_pose, self.ev_track, self._track_pending = torch.cuda.Event(), torch.cuda.Event(), False
 
     def stream_ptr(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -82,17 +86,33 @@ class FramePipeline(object):
         hm = self.net.heatmaps(x)
         if time_events is not None:
             time_events[1].record()
+        if self._track_pending:                          # the previous frame's exchange still reads the buffer decode overwrites
+            torch.cuda.current_stream(self.device).wait_event(self.ev_track)
         self.net.decode(hm, view_of, slot_of, boxes, self.crop_gather.send)
 
     def track_step_crops(self, frame_id, n_det, select, fetch=True):
         """n_det (C,) int32 and select (CropGather.select_index) are the same on every rank (they follow from the frame's box
         list); the keypoint rows come from ``crop_gather.send`` of the rank that owns each crop."""
-        det = self.crop_gather.gather(select)
-        st = self.stream_ptr()
-        self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
-        if fetch:
-            self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
+        if self.track_stream is None:
+            det = self.crop_gather.gather(select)
+            st = self.stream_ptr()
+            self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
+            if fetch:
+                self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
+            return
+        self.ev_pose.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.track_stream):
+            self.track_stream.wait_event(self.ev_pose)
+            det = self.crop_gather.gather(select)
+            st = self.track_stream.cuda_stream
+            self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
+            if fetch:
+                self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
+            self.ev_track.record(self.track_stream)
+        self._track_pending = True
 
     def results(self):
+        if self.track_stream is not None:
+            self.track_stream.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
         return self.handle.decode(0, self.out_i.numpy(), self.out_d.numpy())
