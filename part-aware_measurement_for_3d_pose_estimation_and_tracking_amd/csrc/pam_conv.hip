@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/pam.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;     // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
@@ -359,6 +360,9 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     };
 #define C3_STAMP(k) do { if ((a.dbg & 64) && tid == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     C3_STAMP(0);
+    f32x4 bias4[NTW];                                   // lane group g ends with channels n0 + 4*NTW*g + 4*j + r (see the epilogue)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!(a.dbg & 1)) gload_w(0);                       // in flight while the patch descriptors are computed
 
     // ---- per-thread patch piece descriptors (fixed over the chunk loop) -------------------------------------------------
@@ -394,11 +398,12 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
         }
     };
 
+    // accumulators start from the bias (loaded first of all, so waiting for it never waits for the tile loads behind it)
     f32x4 acc[MT][NTW];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) acc[i][j] = bias4[j];
 
     // slot of this lane in M tile i: p = wave*16*MT + i*16 + (lane & 15); A byte offset = p * PITCH_A (+ tap, + k slice)
     const int p_lane = wave * 16 * MT + (lane & 15);
@@ -475,36 +480,53 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     // wide (the store tail is issue-bound), and the 4 lane groups of a pixel cover the slab's 32*NTW contiguous bytes.
     C3_STAMP(60);
     if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)acc[0][0][0]; return; }
-    f32x4 bias4[NTW];
+    // RES / RELU are compile-time in the HRNet instantiations (a uniform branch picks one of four copies): per 4 values the
+    // epilogue is then 4 unpack + 4 add (residual only), 2 v_cvt_pk_bf16_f32 and ReLU as ONE packed integer max per dword
+    // (bf16 is sign-magnitude: max(int16, 0) clears exactly the negative values) -- the tail is VALU-issue bound.
+    auto epilogue = [&](auto RESC, auto RELUC, auto GENC) {
+        constexpr bool RES = decltype(RESC)::value, RELU = decltype(RELUC)::value, GEN = decltype(GENC)::value;
+        typedef __attribute__((ext_vector_type(2))) short s16x2;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i) {
+            const int p = wave * 16 * MT + i * 16 + (lane & 15);
+            const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
+            if (p < nslots && px < a.W) {
+                uint32_t ov[2 * NTW];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int p = wave * 16 * MT + i * 16 + (lane & 15);
-        const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
-        if (p < nslots && px < a.W) {
-            uint32_t ov[2 * NTW];
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                float v[4];
-                const float r0 = bf16_to_f32((uint16_t)(rres[i][2 * j] & 0xffffu)), r1 = bf16_to_f32((uint16_t)(rres[i][2 * j] >> 16));
-                const float r2 = bf16_to_f32((uint16_t)(rres[i][2 * j + 1] & 0xffffu)), r3 = bf16_to_f32((uint16_t)(rres[i][2 * j + 1] >> 16));
-                const float rr[4] = {r0, r1, r2, r3};
-                if constexpr (!c3_general_act(CIN)) {   // HRNet-only widths: codes 0 / 1, minimal epilogue
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[i][j][r] + bias4[j][r];
-                        if (a.res) v[r] += rr[r];
-                        if (a.relu) v[r] = fmaxf(v[r], 0.0f);
+                for (int j = 0; j < NTW; ++j) {
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    float rr[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (GEN ? (a.res != nullptr) : RES) {
+                        rr[0] = __builtin_bit_cast(float, rres[i][2 * j] << 16); rr[1] = __builtin_bit_cast(float, rres[i][2 * j] & 0xffff0000u);
+                        rr[2] = __builtin_bit_cast(float, rres[i][2 * j + 1] << 16); rr[3] = __builtin_bit_cast(float, rres[i][2 * j + 1] & 0xffff0000u);
                     }
-                } else {
+                    if constexpr (GEN) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = epi_act(acc[i][j][r] + bias4[j][r], a.res ? rr[r] : 0.0f, a.relu);
+                        for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], rr[r], a.relu);
+                        ov[2 * j] = pack_bf16x2(v[0], v[1]); ov[2 * j + 1] = pack_bf16x2(v[2], v[3]);
+                    } else {
+                        if constexpr (RES) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                        }
+                        ov[2 * j] = pack_bf16x2(v[0], v[1]); ov[2 * j + 1] = pack_bf16x2(v[2], v[3]);
+                        if constexpr (RELU) {
+                            ov[2 * j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j]), (s16x2){0, 0}));
+                            ov[2 * j + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j + 1]), (s16x2){0, 0}));
+                        }
+                    }
                 }
-                ov[2 * j] = pack_bf16x2(v[0], v[1]); ov[2 * j + 1] = pack_bf16x2(v[2], v[3]);
+                c3_row_store<NTW>(a.out + (((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4 * NTW, g, ov);
             }
-            c3_row_store<NTW>(a.out + (((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4 * NTW, g, ov);
         }
+    };
+    typedef std::true_type T_; typedef std::false_type F_;
+    if constexpr (c3_general_act(CIN)) {
+        epilogue(F_{}, F_{}, T_{});
+    } else if (a.res) {
+        if (a.relu) epilogue(T_{}, T_{}, F_{}); else epilogue(T_{}, F_{}, F_{});
+    } else {
+        if (a.relu) epilogue(F_{}, T_{}, F_{}); else epilogue(F_{}, F_{}, F_{});
     }
     C3_STAMP(61);
 }
