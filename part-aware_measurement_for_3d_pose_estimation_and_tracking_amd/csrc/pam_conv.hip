@@ -47,6 +47,43 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define OOB_OFFSET 0x80000000u          // beyond any buffer's num_records: the hardware bounds check returns zeros
 
+// One lane's row piece of 4*NTW contiguous bf16 channels (8*NTW bytes at byte offset o, 8-byte aligned; 16-byte aligned
+// when NTW is even or the lane group g is even) as 16-byte accesses where possible.  NTW = 3 (24 bytes) splits 16 + 8 for
+// even g and 8 + 16 for odd g, so the 16-byte half is always aligned.
+template <int NTW>
+__device__ __forceinline__ void c3_row_load(__amdgpu_buffer_rsrc_t rs, unsigned o, int g, uint32_t* d) {
+    if constexpr (NTW == 1) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, o, 0, 0); d[0] = v[0]; d[1] = v[1];
+    } else if constexpr (NTW == 2) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    } else if constexpr (NTW == 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0), w = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16, 0, 0);
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; d[4] = w[0]; d[5] = w[1]; d[6] = w[2]; d[7] = w[3];
+    } else {
+        static_assert(NTW == 3, "slab width");
+        const bool odd = g & 1;
+        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, o + (odd ? 8u : 0u), 0, 0);
+        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs, o + (odd ? 0u : 16u), 0, 0);
+        d[0] = odd ? h[0] : q[0]; d[1] = odd ? h[1] : q[1]; d[2] = odd ? q[0] : q[2];
+        d[3] = odd ? q[1] : q[3]; d[4] = odd ? q[2] : h[0]; d[5] = odd ? q[3] : h[1];
+    }
+}
+template <int NTW>
+__device__ __forceinline__ void c3_row_store(uint16_t* p, int g, const uint32_t* d) {
+    if constexpr (NTW == 1) {
+        *(u32x2*)p = (u32x2){d[0], d[1]};
+    } else if constexpr (NTW == 2) {
+        *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]};
+    } else if constexpr (NTW == 4) {
+        *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]}; *(u32x4*)(p + 8) = (u32x4){d[4], d[5], d[6], d[7]};
+    } else {
+        const bool odd = g & 1;
+        *(u32x4*)(p + (odd ? 4 : 0)) = odd ? (u32x4){d[2], d[3], d[4], d[5]} : (u32x4){d[0], d[1], d[2], d[3]};
+        *(u32x2*)(p + (odd ? 0 : 8)) = odd ? (u32x2){d[0], d[1]} : (u32x2){d[4], d[5]};
+    }
+}
+
+
 // Block tile: BM = 64*WM output pixels x BN = 16*NTW*WN output channels; each wave owns 64 pixels x 16*NTW channels
 // (4 x NTW accumulator tiles of 16x16).  K is walked in chunks of 64; chunk c+1 is fetched (buffer_load, zero-fill by the
 // descriptor's range check, no branches) while chunk c is multiplied out of LDS.
@@ -91,7 +128,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < BPT; ++i) {
         const int p = tid + i * T;
-        woff[i] = (p < BN * 8) ? (unsigned)(((size_t)(n0 + (p >> 3)) * a.Kpad + (p & 7) * 8) * 2) : OOB_OFFSET;
+        // LDS weight row wn*16*NTW + j*16 + q holds output channel wn*16*NTW + 4*NTW*(q >> 2) + 4*j + (q & 3): as the MFMA A operand
+        // this leaves every lane with 4*NTW contiguous channels of its pixel (same scheme as k_conv3x3)
+        const int row = p >> 3, wnb = row / (16 * NTW), rem = row - wnb * 16 * NTW, q = rem & 15;
+        const int ch = wnb * 16 * NTW + 4 * NTW * (q >> 2) + 4 * (rem >> 4) + (q & 3);
+        woff[i] = (p < BN * 8) ? (unsigned)(((size_t)(n0 + ch) * a.Kpad + (p & 7) * 8) * 2) : OOB_OFFSET;
     }
 
     u32x4 areg[APT], breg[BPT];
@@ -127,11 +168,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
         while (kc_c >= a.Cin) { kc_c -= a.Cin; ++kc_tap; }
     };
 
-    f32x4 acc[4][NTW];
+    const int g = lane >> 4, cw0 = n0 + wn * 16 * NTW;
+    f32x4 acc[4][NTW];                                  // [pixel tile][channel tile], started from the bias
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < NTW; ++j) {
+        const f32x4 b4 = a.bias ? *(const f32x4*)(a.bias + cw0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) acc[i][j] = b4;
+    }
 
     const int nchunks = a.Kpad / KC;
     load_chunk();
@@ -160,54 +204,49 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[ks][i]),
-                                                                       __builtin_bit_cast(bf16x8_t, bfr[ks][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[ks][j]),
+                                                                       __builtin_bit_cast(bf16x8_t, af[ks][i]), acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < nchunks) { store_chunk(buf ^ 1); advance(); }
         __syncthreads();
     }
 
-    // epilogue.  D tile (16x16): column = lane & 15 (channel), rows = (lane >> 4) * 4 + r (pixels).  The wave's 64 x 16*NTW
-    // tile goes through LDS (fp32, + bias) so that residual loads and output stores are 16 B per lane over whole pixels.
-    constexpr int P = 16 * NTW + 4;                     // floats per staged pixel row (pad keeps 16-B alignment, breaks banks)
-    float* Ew = (float*)smem + (size_t)wave * 64 * P;
+    // epilogue straight from the accumulators: with the weights as the A operand the D tile has channels on its rows, so this
+    // lane holds channels cw0 + 4*NTW*g + 4*j + r of pixel mw0 + i*16 + (lane & 15): 4*NTW contiguous channels, 16-byte accesses
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.M * a.Cout * 2), 0x00020000);
+    const int mw0 = m0 + wm * 64;
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-        const float b = a.bias ? a.bias[n0 + wn * 16 * NTW + j * 16 + (lane & 15)] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Ew[(i * 16 + (lane >> 4) * 4 + r) * P + j * 16 + (lane & 15)] = acc[i][j][r] + b;
-    }
-    __syncthreads();
-    constexpr int PPX = 2 * NTW;                        // 16-byte output pieces per pixel of this wave's channel span
-    const int mw0 = m0 + wm * 64, cw0 = n0 + wn * 16 * NTW;
-#pragma unroll
-    for (int t = 0; t < PPX; ++t) {
-        const int q = lane + 64 * t;
-        const int px = q / PPX, c8 = q - px * PPX;
-        const int m = mw0 + px;
+    for (int i = 0; i < 4; ++i) {
+        const int m = mw0 + i * 16 + (lane & 15);
         if (m < a.M) {
-            const f32x4 v0 = *(const f32x4*)(Ew + px * P + c8 * 8);
-            const f32x4 v1 = *(const f32x4*)(Ew + px * P + c8 * 8 + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            const size_t o = (size_t)m * a.Cout + cw0 + c8 * 8;
-            float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (a.res) {
-                const bf16x8 rr = *(const bf16x8*)(a.res + o);
+            const size_t o = (size_t)m * a.Cout + cw0 + g * 4 * NTW;
+            uint32_t rres[2 * NTW], ov[2 * NTW];
+            if (a.res) c3_row_load<NTW>(rs_res, (unsigned)(o * 2), g, rres);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) rv[k] = bf16_to_f32((uint16_t)rr[k]);
+            for (int j = 0; j < NTW; ++j) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float rr[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.res) {
+                    rr[0] = __builtin_bit_cast(float, rres[2 * j] << 16); rr[1] = __builtin_bit_cast(float, rres[2 * j] & 0xffff0000u);
+                    rr[2] = __builtin_bit_cast(float, rres[2 * j + 1] << 16); rr[3] = __builtin_bit_cast(float, rres[2 * j + 1] & 0xffff0000u);
+                }
+                if constexpr (GEN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], rr[r], a.relu);
+                    ov[2 * j] = pack_bf16x2(v[0], v[1]); ov[2 * j + 1] = pack_bf16x2(v[2], v[3]);
+                } else {                                // HRNet's codes 0 / 1; ReLU as a packed int16 max on the bf16 pairs
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                    ov[2 * j] = pack_bf16x2(v[0], v[1]); ov[2 * j + 1] = pack_bf16x2(v[2], v[3]);
+                    if (a.relu) {
+                        ov[2 * j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j]), (s16x2){0, 0}));
+                        ov[2 * j + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j + 1]), (s16x2){0, 0}));
+                    }
+                }
             }
-            bf16x8 ov;
-            if constexpr (!GEN) {                   // HRNet's codes 0 / 1: their own instantiation, minimal epilogue
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const float t = v[k] + rv[k]; ov[k] = (short)f32_to_bf16_rne(a.relu ? fmaxf(t, 0.0f) : t); }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) ov[k] = (short)f32_to_bf16_rne(epi_act(v[k], rv[k], a.relu));
-            }
-            *(bf16x8*)(a.out + o) = ov;
+            c3_row_store<NTW>(a.out + o, g, ov);
         }
     }
 }
@@ -282,42 +321,6 @@ __device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((flo
 
 // the deep small-image layers run one workgroup per CU (one wave per SIMD): give those instantiations the whole register
 // file, otherwise the scheduler, starved by the chunk-prefetch registers, reads each MFMA fragment right before its use
-// One lane's row piece of 4*NTW contiguous bf16 channels (8*NTW bytes at byte offset o, 8-byte aligned; 16-byte aligned
-// when NTW is even or the lane group g is even) as 16-byte accesses where possible.  NTW = 3 (24 bytes) splits 16 + 8 for
-// even g and 8 + 16 for odd g, so the 16-byte half is always aligned.
-template <int NTW>
-__device__ __forceinline__ void c3_row_load(__amdgpu_buffer_rsrc_t rs, unsigned o, int g, uint32_t* d) {
-    if constexpr (NTW == 1) {
-        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, o, 0, 0); d[0] = v[0]; d[1] = v[1];
-    } else if constexpr (NTW == 2) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0); d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    } else if constexpr (NTW == 4) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0), w = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16, 0, 0);
-        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; d[4] = w[0]; d[5] = w[1]; d[6] = w[2]; d[7] = w[3];
-    } else {
-        static_assert(NTW == 3, "slab width");
-        const bool odd = g & 1;
-        const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rs, o + (odd ? 8u : 0u), 0, 0);
-        const u32x2 h = __builtin_amdgcn_raw_buffer_load_b64(rs, o + (odd ? 0u : 16u), 0, 0);
-        d[0] = odd ? h[0] : q[0]; d[1] = odd ? h[1] : q[1]; d[2] = odd ? q[0] : q[2];
-        d[3] = odd ? q[1] : q[3]; d[4] = odd ? q[2] : h[0]; d[5] = odd ? q[3] : h[1];
-    }
-}
-template <int NTW>
-__device__ __forceinline__ void c3_row_store(uint16_t* p, int g, const uint32_t* d) {
-    if constexpr (NTW == 1) {
-        *(u32x2*)p = (u32x2){d[0], d[1]};
-    } else if constexpr (NTW == 2) {
-        *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]};
-    } else if constexpr (NTW == 4) {
-        *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]}; *(u32x4*)(p + 8) = (u32x4){d[4], d[5], d[6], d[7]};
-    } else {
-        const bool odd = g & 1;
-        *(u32x4*)(p + (odd ? 4 : 0)) = odd ? (u32x4){d[2], d[3], d[4], d[5]} : (u32x4){d[0], d[1], d[2], d[3]};
-        *(u32x2*)(p + (odd ? 0 : 8)) = odd ? (u32x2){d[0], d[1]} : (u32x2){d[4], d[5]};
-    }
-}
-
 template <int CIN, int NTW, int MT, int NWAVES, int PMAX>
 __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_conv3x3(C3Args a) {
     constexpr int T = 64 * NWAVES, BN = 16 * NTW;
