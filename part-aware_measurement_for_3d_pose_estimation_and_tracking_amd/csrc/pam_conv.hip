@@ -267,18 +267,16 @@ static int launch_conv(hipStream_t s, const ConvArgs& a) {
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
-// tile choice: widest block tile that still gives the chip >= ~2 workgroups per CU, else the smallest
+// tile choice: share the staged input tile between two N tiles when there are two; otherwise 128-pixel blocks while they still
+// give the chip >= 2 workgroups per CU, else 64-pixel blocks
 template <int NTW>
 static int dispatch_conv(hipStream_t s, const ConvArgs& a, int force) {
     const int nb = a.Cout / (16 * NTW);                 // N tiles of one wave
     auto blocks = [&](int wm, int wn) { return (long)((a.M + 64 * wm - 1) / (64 * wm)) * (nb / wn); };
     int cfg = force;
-    if (cfg < 0) {
-        if (nb % 2 == 0 && blocks(2, 2) >= 512) cfg = 3;
-        else if (blocks(4, 1) >= 512) cfg = 4;
-        else if (blocks(2, 1) >= 512) cfg = 2;
-        else if (nb % 2 == 0 && blocks(1, 2) >= 384) cfg = 1;
-        else cfg = 0;
+    if (cfg < 0) {                                      // measured per HRNet layer shape with tools/bench_conv.py --tiles=...
+        if (nb % 2 == 0) cfg = blocks(2, 2) >= 400 ? 3 : 1;   // two N tiles per workgroup: the input tile is staged once for both
+        else cfg = blocks(2, 1) >= 512 ? 2 : 0;
     }
     switch (cfg) {
         case 0: return launch_conv<NTW, 1, 1>(s, a);
