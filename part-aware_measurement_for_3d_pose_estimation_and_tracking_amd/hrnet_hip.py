@@ -168,7 +168,7 @@ class HipHRNet(ConvEngine):
         self._pack(folded_model, device)
         self.tile_cfg = -1
         # concurrency: the 2-4 branches of an HR module run on side streams (the coarse branches do not fill the chip)
-        self.side = [torch.cuda.Stream(device) for _ in range(3)]
+        self.side = [torch.cuda.Stream(device) for _ in range(3)]     # equal priorities: mixing them costs 1.5-2x (measured)
         self.multi_stream = True
         self.count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
 
