@@ -332,15 +332,19 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2), so give each XCD a contiguous run of
     // tiles -- vertically adjacent tiles re-read each other's halo rows, which then hit that L2 instead of the fabric
-    int bx;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-        bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int ty = bx % a.tiles_y, n = bx / a.tiles_y;
-    const int ty0 = ty * a.TH;
-    const int th = min(a.TH, a.H - ty0);                // ragged last tile
-    const int PW = a.W + 2, npatch = (th + 2) * PW, nslots = th * PW;
+    // Single-chunk layers (Cin = 48) are PERSISTENT: the grid is capped at the resident workgroups and each one walks tiles
+    // v = blockIdx.x, + gridDim.x, ... with the slab's weights staged once and the next tile's patch in flight (registers)
+    // under the current tile's epilogue.  gridDim.x is a multiple of 8 then, so a workgroup stays on its XCD's run.
+    const int ntiles = a.tiles_y * a.N;
+    auto tile_of = [&](int v) {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, loc = v >> 3;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    };
+    int vtile = blockIdx.x;
+    int bx = tile_of(vtile);
+    int n = bx / a.tiles_y, ty0 = (bx - n * a.tiles_y) * a.TH;
+    const int PW = a.W + 2, npatch = (a.TH + 2) * PW;   // full-height patch: rows below a ragged last tile load as zeros
+    int nslots = min(a.TH, a.H - ty0) * PW;
     const int n0 = blockIdx.y * BN;
     char* Wsm = smem + ((((size_t)npatch + 2) * PITCH_A + 15) & ~(size_t)15);   // junk-slot reads past the patch land in the weights (in bounds)
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * CIN * 2), 0x00020000);
@@ -368,43 +372,45 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
 
     // ---- per-thread patch piece descriptors (fixed over the chunk loop) -------------------------------------------------
     unsigned goffA[NPP];
+    int tid_v;
+    auto descriptors = [&](int n_, int ty0_) {
 #pragma unroll
-    for (int i = 0; i < NPP; ++i) {
-        const int q = tid + i * T;
-        goffA[i] = OOB_OFFSET;
-        if (q < npatch * PC8) {
-            const int pp = q / PC8, c8 = q - pp * PC8;
-            const int pyy = fdiv_small(pp, a.inv_pw), pxx = pp - pyy * PW;
-            const int iy = ty0 - 1 + pyy, ix = pxx - 1;
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                goffA[i] = (unsigned)((((size_t)n * a.H + iy) * a.W + ix) * CIN * 2 + c8 * 16);
+        for (int i = 0; i < NPP; ++i) {
+            const int q = tid_v + i * T;
+            goffA[i] = OOB_OFFSET;
+            if (q < npatch * PC8) {
+                const int pp = q / PC8, c8 = q - pp * PC8;
+                const int pyy = fdiv_small(pp, a.inv_pw), pxx = pp - pyy * PW;
+                const int iy = ty0_ - 1 + pyy, ix = pxx - 1;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    goffA[i] = (unsigned)((((size_t)n_ * a.H + iy) * a.W + ix) * CIN * 2 + c8 * 16);
+            }
         }
-    }
+    };
+    tid_v = tid;
+    descriptors(n, ty0);
     auto gload_a = [&](int cc) {
         const unsigned so = (unsigned)(cc * CK * 2);
 #pragma unroll
         for (int i = 0; i < NPP; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, goffA[i], goffA[i] == OOB_OFFSET ? 0 : so, 0);
     };
     auto gload = [&](int cc) { gload_w(cc); gload_a(cc); };
-    auto lstore = [&]() {
+    auto lstore = [&](bool with_weights) {
 #pragma unroll
         for (int i = 0; i < NPP; ++i) {
-            const int q = tid + i * T;
+            const int q = tid_v + i * T;
             if (q < npatch * PC8) { const int pp = q / PC8, c8 = q - pp * PC8; *(u32x4*)(smem + (size_t)pp * PITCH_A + c8 * 16) = ra[i]; }
         }
+        if (with_weights) {
 #pragma unroll
-        for (int i = 0; i < NWP; ++i) {
-            const int q = tid + i * T;
-            if (q < WIMG / 16) *(u32x4*)(Wsm + (size_t)q * 16) = rw[i];
+            for (int i = 0; i < NWP; ++i) {
+                const int q = tid + i * T;
+                if (q < WIMG / 16) *(u32x4*)(Wsm + (size_t)q * 16) = rw[i];
+            }
         }
     };
 
-    // accumulators start from the bias (loaded first of all, so waiting for it never waits for the tile loads behind it)
     f32x4 acc[MT][NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i][j] = bias4[j];
 
     // slot of this lane in M tile i: p = wave*16*MT + i*16 + (lane & 15); A byte offset = p * PITCH_A (+ tap, + k slice)
     const int p_lane = wave * 16 * MT + (lane & 15);
@@ -414,10 +420,28 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     if (a.dbg & 16) { if (goffA[0] == 12345u) a.out[0] = 1; return; }
     if (!(a.dbg & 1)) gload_a(0);
     C3_STAMP(1);
+    if constexpr (NCHUNK == 1) {                        // the slab's only weight chunk is staged once, outside the tile loop
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+            const int q = tid + i * T;
+            if (q < WIMG / 16) *(u32x4*)(Wsm + (size_t)q * 16) = rw[i];
+        }
+    }
+    tid_v = tid;                                        // opaque per iteration: keeps per-piece addresses from being hoisted (VGPRs)
+    for (bool first = true;; first = false) {           // tile loop (one pass unless persistent)
+    if constexpr (NCHUNK == 1) asm volatile("" : "+v"(tid_v));
+    const int vnext = vtile + (int)gridDim.x;
+    const bool has_next = NCHUNK == 1 && vnext < ntiles;
+    int n_nx = 0, ty0_nx = 0;
+    // accumulators start from the bias (loaded first of all, so waiting for it never waits for the tile loads behind it)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i][j] = bias4[j];
     for (int cc = 0; cc < NCHUNK; ++cc) {
-        if (cc > 0) __syncthreads();                    // every wave is done reading the previous chunk
+        if (cc > 0 || !first) __syncthreads();          // every wave is done reading the previous chunk / tile
         C3_STAMP(2 + 4 * cc);
-        if (!(a.dbg & 32)) lstore();
+        if (!(a.dbg & 32)) lstore(NCHUNK > 1);
         C3_STAMP(3 + 4 * cc);
         __syncthreads();
         C3_STAMP(4 + 4 * cc);
@@ -481,6 +505,12 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     // wide (the store tail is issue-bound), and the 4 lane groups of a pixel cover the slab's 32*NTW contiguous bytes.
     C3_STAMP(60);
     if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)acc[0][0][0]; return; }
+    if (has_next) {     // next TILE's patch goes in flight under this tile's epilogue (the fragment registers are free again by now)
+        const int b2 = tile_of(vnext);
+        n_nx = b2 / a.tiles_y; ty0_nx = (b2 - n_nx * a.tiles_y) * a.TH;
+        descriptors(n_nx, ty0_nx);
+        gload_a(0);
+    }
     // RES / RELU are compile-time in the HRNet instantiations (a uniform branch picks one of four copies): per 4 values the
     // epilogue is then 4 unpack + 4 add (residual only), 2 v_cvt_pk_bf16_f32 and ReLU as ONE packed integer max per dword
     // (bf16 is sign-magnitude: max(int16, 0) clears exactly the negative values) -- the tail is VALU-issue bound.
@@ -529,6 +559,9 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     } else {
         if (a.relu) epilogue(F_{}, T_{}, F_{}); else epilogue(F_{}, F_{}, F_{});
     }
+    if (!has_next) break;
+    vtile = vnext; n = n_nx; ty0 = ty0_nx; nslots = min(a.TH, a.H - ty0) * PW;
+    }   // tile loop
     C3_STAMP(61);
 }
 
@@ -542,6 +575,12 @@ static int launch_c3_one(hipStream_t s, const C3Args& a) {
     dim3 grid(a.tiles_y * a.N, a.Cout / (16 * NTW));
     const size_t lds = c3_lds_bytes(CIN, NTW, npatch);
     if (lds > 150 * 1024) return PAM_E_ARG;
+    if (CIN / c3_ck(CIN) == 1 && !(a.dbg & 128)) {      // single-chunk layers: persistent workgroups (see the kernel)
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3<CIN, NTW, MT, NWAVES, PMAX>, 64 * NWAVES, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        const int slots = 256 * per_cu / (int)grid.y / 8 * 8;
+        if (slots >= 8 && (int)grid.x > slots) grid.x = slots;
+    }
     hipLaunchKernelGGL((k_conv3x3<CIN, NTW, MT, NWAVES, PMAX>), grid, dim3(64 * NWAVES), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
