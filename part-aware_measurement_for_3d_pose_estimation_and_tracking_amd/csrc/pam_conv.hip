@@ -768,33 +768,40 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
 // out[n,y,x,c] = [relu](base[n,y,x,c] + sum_t term_t[n, y >> sh_t, x >> sh_t, c]); 8 channels (16 B) per thread
 struct UpArgs { const uint16_t* base; const uint16_t* term[3]; int sh[3]; int nterms; uint16_t* out; int N, H, W, C, relu; };
 __global__ __launch_bounds__(256) void k_upsample_add(UpArgs a) {
-    const size_t total = (size_t)a.N * a.H * a.W * (a.C / 8);
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const int c8 = (int)(e % (a.C / 8));
-        const size_t pix = e / (a.C / 8);
-        const int x = (int)(pix % a.W);
-        const size_t t2 = pix / a.W;
-        const int y = (int)(t2 % a.H), n = (int)(t2 / a.H);
-        bf16x8 b = *(const bf16x8*)(a.base + pix * a.C + c8 * 8);
+    const unsigned C8 = (unsigned)a.C >> 3, total = (unsigned)a.N * a.H * a.W * C8;       // host checks total < 2^31: 32-bit index math
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const unsigned pix = e / C8, c8 = e - pix * C8;
+        const unsigned t2 = pix / (unsigned)a.W, x = pix - t2 * a.W;
+        const unsigned n = t2 / (unsigned)a.H, y = t2 - n * a.H;
+        const bf16x8 b = *(const bf16x8*)(a.base + (size_t)pix * a.C + c8 * 8);
+        bf16x8 q[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {                   // all term loads issued together (independent addresses)
+            q[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < a.nterms) {
+                const unsigned hs = (unsigned)a.H >> a.sh[t], ws = (unsigned)a.W >> a.sh[t];
+                q[t] = *(const bf16x8*)(a.term[t] + ((size_t)(n * hs + (y >> a.sh[t])) * ws + (x >> a.sh[t])) * a.C + c8 * 8);
+            }
+        }
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32((uint16_t)b[k]);
-        for (int t = 0; t < a.nterms; ++t) {
-            const int hs = a.H >> a.sh[t], ws = a.W >> a.sh[t];
-            const bf16x8 q = *(const bf16x8*)(a.term[t] + (((size_t)n * hs + (y >> a.sh[t])) * ws + (x >> a.sh[t])) * a.C + c8 * 8);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32((uint16_t)q[k]);
-        }
+        for (int t = 0; t < 3; ++t)                     // same summation order as before: base, then terms in order
+            if (t < a.nterms) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32((uint16_t)q[t][k]);
+            }
         bf16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (short)f32_to_bf16_rne(a.relu ? fmaxf(v[k], 0.0f) : v[k]);
-        *(bf16x8*)(a.out + pix * a.C + c8 * 8) = o;
+        *(bf16x8*)(a.out + (size_t)pix * a.C + c8 * 8) = o;
     }
 }
 
 extern "C" int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, const void* const* terms,
                                           const int32_t* shifts, void* out, int N, int H, int W, int C, int relu) {
-    if (!base || !out || n_terms < 0 || n_terms > 3 || C % 8 != 0) return PAM_E_ARG;
+    if (!base || !out || n_terms < 0 || n_terms > 3 || C % 8 != 0 || (size_t)N * H * W * (C / 8) >= (1ull << 31)) return PAM_E_ARG;
     UpArgs a;
     a.base = (const uint16_t*)base; a.out = (uint16_t*)out; a.nterms = n_terms;
     for (int t = 0; t < 3; ++t) { a.term[t] = t < n_terms ? (const uint16_t*)terms[t] : nullptr; a.sh[t] = t < n_terms ? shifts[t] : 0; }
