@@ -164,9 +164,9 @@ int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw
  * with Cin in {48,64,96,128,192,256,384,512}): the same weights pre-packed as per-chunk LDS images [Cout/BN][Cin/CK][BN][9*CK + pad] (BN =
  * pam_conv3x3_slab(H, W, Cin, Cout); CK = 48 if Cin == 48, 64 if Cin >= 192, else 32; row pitch 864 / 1184 / 608 bytes;
  * row j*16 + q of a slab, q < 16, j < BN/16, holds output channel 4*(BN/16)*(q >> 2) + 4*j + (q & 3) of that slab) for the
- * rows-in-LDS kernel k_conv3x3; for the stem layer (Cin 8, Cout 64, 3x3, stride 2, pad 1) w_img is instead the 12 MFMA A
- * fragments of k_conv_stem, [j < 4][ky < 3][lane < 64][8] bf16: lane l = input channels 0..7 of tap (ky, kx = l >> 4; zero for
- * l >= 48) of output channel 16*((l & 15) >> 2) + 4*j + (l & 3).  NULL = generic kernel.
+ * rows-in-LDS kernel k_conv3x3; for a stem layer (Cin 8, Cout 32 or 64, 3x3, stride 1 or 2, pad 1; Cout 32 is accepted only
+ * here) w_img is instead the MFMA A fragments of k_conv_stem, [j < Cout/16][ky < 3][lane < 64][8] bf16: lane l = input channels
+ * 0..7 of tap (ky, kx = l >> 4; zero for l >= 48) of output channel (Cout/4)*((l & 15) >> 2) + 4*j + (l & 3).  NULL = generic kernel.
  * pam_upsample_add_nhwc_bf16: the HRNet fuse-layer sum out = [relu](base + sum_t nearest_upsample(term_t, 2^shift_t)). */
 int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                          const void* residual, void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,

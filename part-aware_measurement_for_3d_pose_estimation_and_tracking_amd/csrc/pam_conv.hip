@@ -627,8 +627,8 @@ extern "C" int pam_conv3x3_slab(int H, int W, int Cin, int Cout) {
 }
 
 // ====================================================================================================================
-// k_conv_stem: the first convolution of both networks' stems -- 3x3 / stride 2 / pad 1 from the 8-channel (RGB + zeros) input
-// to 64 channels.  K per tap ROW is 3 taps x 8 channels = 24 <= 32, so one v_mfma_f32_16x16x32_bf16 covers a whole tap row:
+// k_conv_stem: the first convolution of both networks' stems -- 3x3 / stride 1 or 2 / pad 1 from the 8-channel (RGB + zeros)
+// input to 32 or 64 channels.  K per tap ROW is 3 taps x 8 channels = 24 <= 32, so one v_mfma_f32_16x16x32_bf16 covers a whole tap row:
 // lane (pixel l & 15, k-group g = l >> 4) supplies as its B fragment the 16-byte input pixel (2y + ky - 1, 2x + g - 1)
 // straight from global memory (g = 3 and the zero padding come from the buffer bounds check), 3 loads and 12 MFMAs per
 // 16 output pixels x 64 channels.  The weights (A operand, 12 fragments) live in registers for the wave's whole row; their
@@ -636,6 +636,7 @@ extern "C" int pam_conv3x3_slab(int H, int W, int Cin, int Cout) {
 // by 4 lanes x 2 x 16 B.  Pure streaming: ~35 MB in, ~71 MB out at 20 crops.  One wave per output row.
 // ====================================================================================================================
 struct StemArgs { const uint16_t* in; const uint16_t* wfrag; const float* bias; uint16_t* out; int N, H, W, Ho, Wo, relu; };
+template <int S, int NT>                                // S = stride (1: Darknet's first layer, 2: HRNet's), NT = Cout / 16 (2 or 4)
 __global__ __launch_bounds__(256) void k_conv_stem(StemArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row_id = blockIdx.x * 4 + wave;
@@ -643,23 +644,23 @@ __global__ __launch_bounds__(256) void k_conv_stem(StemArgs a) {
     const int n = row_id / a.Ho, oy = row_id - n * a.Ho;
     const int px = lane & 15, g = lane >> 4;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * 16), 0x00020000);
-    bf16x8 wf[4][3];
+    bf16x8 wf[NT][3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) wf[j][ky] = *(const bf16x8*)(a.wfrag + ((size_t)(j * 3 + ky) * 64 + lane) * 8);
-    f32x4 bias4[4];
+    f32x4 bias4[NT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + g * 16 + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    unsigned rowoff[3];                                  // byte offset of input row 2*oy + ky - 1, or OOB
+    for (int j = 0; j < NT; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + g * 4 * NT + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned rowoff[3];                                  // byte offset of input row S*oy + ky - 1, or OOB
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = 2 * oy + ky - 1;
+        const int iy = S * oy + ky - 1;
         rowoff[ky] = (iy >= 0 && iy < a.H && g < 3) ? (unsigned)((((size_t)n * a.H + iy) * a.W) * 16) : OOB_OFFSET;
     }
     const int ntiles = (a.Wo + 15) >> 4;
     auto load_tile = [&](int t, bf16x8* b) {
-        const int ix = 2 * (t * 16 + px) + g - 1;
+        const int ix = S * (t * 16 + px) + g - 1;
         const bool ok = ix >= 0 && ix < a.W;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -667,29 +668,28 @@ __global__ __launch_bounds__(256) void k_conv_stem(StemArgs a) {
     };
     bf16x8 cur[3], nxt[3];
     load_tile(0, cur);
-    uint16_t* orow = a.out + (((size_t)n * a.Ho + oy) * a.Wo) * 64 + g * 16;
+    uint16_t* orow = a.out + (((size_t)n * a.Ho + oy) * a.Wo) * (16 * NT) + g * 4 * NT;
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) load_tile(t + 1, nxt);
-        f32x4 acc[4];
+        f32x4 acc[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = bias4[j];
+        for (int j = 0; j < NT; ++j) acc[j] = bias4[j];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[j][ky]), __builtin_bit_cast(bf16x8_t, cur[ky]), acc[j], 0, 0, 0);
         const int ox = t * 16 + px;
         if (ox < a.Wo) {
-            uint32_t d[8];
+            uint32_t d[2 * NT];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = epi_act1(acc[j][r], a.relu & 3);
                 d[2 * j] = pack_bf16x2(v[0], v[1]); d[2 * j + 1] = pack_bf16x2(v[2], v[3]);
             }
-            *(u32x4*)(orow + (size_t)ox * 64) = (u32x4){d[0], d[1], d[2], d[3]};
-            *(u32x4*)(orow + (size_t)ox * 64 + 8) = (u32x4){d[4], d[5], d[6], d[7]};
+            c3_row_store<NT>(orow + (size_t)ox * (16 * NT), g, d);
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) cur[ky] = nxt[ky];
@@ -699,7 +699,8 @@ __global__ __launch_bounds__(256) void k_conv_stem(StemArgs a) {
 extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                                     const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
                                     int KH, int KW, int stride, int pad, int relu, int tile_cfg) {
-    if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || (Cout % 48 != 0 && Cout % 64 != 0) ||
+    const bool stem32 = w_img && Cin == 8 && Cout == 32 && KH == 3 && KW == 3 && pad == 1 && !residual && tile_cfg < 0 && stride <= 2;
+    if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || (Cout % 48 != 0 && Cout % 64 != 0 && !stem32) ||
         KH < 1 || KW < 1 || KH > 3 || KW > 3 || stride < 1)
         return PAM_E_ARG;
     ConvArgs a;
@@ -709,11 +710,17 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.Ktot = KH * KW * Cin; a.Kpad = (a.Ktot + KC - 1) / KC * KC; a.M = N * a.Ho * a.Wo;
     if (H >= 32768 || W >= 32768) return PAM_E_ARG;
-    if (w_img && Cin == 8 && Cout == 64 && KH == 3 && KW == 3 && stride == 2 && pad == 1 && !residual && tile_cfg < 0) {
-        StemArgs t;                                      // w_img = the 12 pre-permuted A fragments (see pam.h)
+    if (w_img && Cin == 8 && (Cout == 64 || Cout == 32) && KH == 3 && KW == 3 && (stride == 1 || stride == 2) && pad == 1 &&
+        !residual && tile_cfg < 0) {
+        StemArgs t;                                      // w_img = the pre-permuted A fragments (see pam.h)
         t.in = a.in; t.wfrag = (const uint16_t*)w_img; t.bias = bias; t.out = a.out;
         t.N = N; t.H = H; t.W = W; t.Ho = a.Ho; t.Wo = a.Wo; t.relu = relu;
-        hipLaunchKernelGGL(k_conv_stem, dim3((N * a.Ho + 3) / 4), dim3(256), 0, (hipStream_t)stream, t);
+        const dim3 grid((N * a.Ho + 3) / 4), blk(256);
+        hipStream_t s = (hipStream_t)stream;
+        if (stride == 2 && Cout == 64) hipLaunchKernelGGL((k_conv_stem<2, 4>), grid, blk, 0, s, t);
+        else if (stride == 2) hipLaunchKernelGGL((k_conv_stem<2, 2>), grid, blk, 0, s, t);
+        else if (Cout == 64) hipLaunchKernelGGL((k_conv_stem<1, 4>), grid, blk, 0, s, t);
+        else hipLaunchKernelGGL((k_conv_stem<1, 2>), grid, blk, 0, s, t);
         return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
     }
     if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&

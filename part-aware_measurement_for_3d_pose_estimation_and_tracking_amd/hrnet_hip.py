@@ -28,7 +28,8 @@ class PackedConv(object):
             w = torch.cat([w, torch.zeros(pad_cout_to - cout, cin, kh, kw)], dim=0)
             b = torch.cat([b, torch.zeros(pad_cout_to - cout)])
             cout = pad_cout_to
-        assert cin % 8 == 0 and (cout % 48 == 0 or cout % 64 == 0), (cin, cout)
+        stem = cin == 8 and cout in (32, 64) and kh == 3 and kw == 3 and conv.stride[0] in (1, 2) and conv.padding[0] == 1
+        assert cin % 8 == 0 and (cout % 48 == 0 or cout % 64 == 0 or stem), (cin, cout)
         ktot = kh * kw * cin
         kpad = (ktot + 63) // 64 * 64
         wp = torch.zeros((cout, kpad), dtype=torch.float32)
@@ -42,15 +43,16 @@ class PackedConv(object):
                                                               cin in (48, 64, 96, 128, 192, 256, 384, 512)) else None
         self._images = {}
         self._device = device
-        # stem convolution (8 -> 64 channels, 3x3 stride 2): the 12 MFMA A fragments of k_conv_stem, [n-tile j][ky][lane][8]:
-        # lane l holds, for output channel 16*((l & 15) >> 2) + 4*j + (l & 3), the 8 input channels of tap (ky, kx = l >> 4)
+        # stem convolution (8 -> 32 / 64 channels, 3x3, stride 1 / 2): the MFMA A fragments of k_conv_stem, [n-tile j][ky][lane][8]:
+        # lane l holds, for output channel 4*nt*((l & 15) >> 2) + 4*j + (l & 3), the 8 input channels of tap (ky, kx = l >> 4)
         self._stem = None
-        if cin == 8 and cout == 64 and kh == 3 and kw == 3 and self.stride == 2 and self.pad == 1:
+        if stem:
+            nt = cout // 16
             lanes = torch.arange(64)
             q, kx = lanes & 15, lanes >> 4
-            frag = torch.zeros((4, 3, 64, 8), dtype=torch.float32)
-            for j in range(4):
-                ch = 16 * (q >> 2) + 4 * j + (q & 3)
+            frag = torch.zeros((nt, 3, 64, 8), dtype=torch.float32)
+            for j in range(nt):
+                ch = 4 * nt * (q >> 2) + 4 * j + (q & 3)
                 for ky in range(3):
                     sel = kx < 3
                     frag[j, ky, sel] = w[ch[sel], :, ky, kx[sel]]

@@ -258,7 +258,9 @@ class HipDarknet(ConvEngine):
             b, t = layers[i], layers[i]['type']
             if t == 'convolutional':
                 cin_pad = c_pad if i == 0 else padded[i - 1]
-                op = PackedConv(fold_conv(model.mods[i]), device, pad_cin_to=cin_pad, pad_cout_to=_round_channels(b['filters']))
+                stem = i == 0 and cin_pad == 8 and b['size'] == 3 and b['pad'] and b['stride'] in (1, 2) and b['filters'] in (32, 64)
+                op = PackedConv(fold_conv(model.mods[i]), device, pad_cin_to=cin_pad,
+                                pad_cout_to=None if stem else _round_channels(b['filters']))      # k_conv_stem writes 32 real channels
                 nxt = layers[i + 1] if i + 1 < n else None
                 fuse = (nxt is not None and nxt['type'] == 'shortcut' and nxt['activation'] == 'linear' and used_by[i] == [] and
                         b['activation'] in ('leaky', 'linear'))

@@ -33,7 +33,9 @@ def _engine():
     (1, 104, 104, 64, 128, 3, 1, 'leaky', 'after'),     # wide rows: one-row tiles on a 3-wave block
     (1, 208, 208, 64, 64, 3, 1, 'leaky', 'after'),      # rows too wide for the patch kernel -> generic kernel
     (2, 13, 13, 1024, 256, 1, 1, 'linear', 'none'),     # head conv (255 -> 256 padded below)
-    (2, 30, 22, 8, 64, 3, 1, 'leaky', 'none'),          # first conv, padded 3 -> 8 / 32 -> 64
+    (2, 30, 22, 8, 64, 3, 1, 'leaky', 'none'),          # first conv on the stem kernel, stride 1
+    (2, 31, 23, 8, 32, 3, 1, 'leaky', 'none'),          # Darknet's own first layer: 32 real channels, ragged width
+    (2, 31, 23, 8, 32, 3, 2, 'relu', 'none'),
     (2, 30, 22, 64, 64, 3, 2, 'leaky', 'none'),
     (2, 24, 18, 48, 48, 3, 1, 'leaky', 'before'),
     (2, 24, 18, 48, 48, 3, 1, 'relu', 'after'),

@@ -60,7 +60,8 @@ def test_launch_plan_on_meta():
     kinds = [s[0] for s in hd.plan]
     assert kinds.count('conv') == 75 and kinds.count('upcat') == 2 and kinds.count('add') == 0 and kinds.count('head') == 3
     assert sum(1 for s in hd.plan if s[0] == 'conv' and s[5] is not None) == 23          # every shortcut fused into its conv
-    assert hd.padded[0] == 64 and hd.real[0] == 32 and hd.padded[81] == 256 and hd.real[81] == 255
+    assert hd.padded[0] == 32 and hd.real[0] == 32 and hd.padded[2] == 64 and hd.real[2] == 32          # stem kernel writes 32 real channels
+    assert hd.padded[81] == 256 and hd.real[81] == 255
     hd.count = dict(bytes=0, flops=0, launches=0)
     x8 = torch.empty((2, 8, 416, 416), dtype=torch.bfloat16, device='meta').contiguous(memory_format=torch.channels_last)
     heads = hd.forward(x8)
