@@ -88,7 +88,7 @@ class ivclabpose(object):
                                         weight if weight and os.path.exists(weight) else None,
                                         names if names and os.path.exists(names) else None,
                                         score_thresh=_cfg(d, 'SCORE_THRESH'), nms_thresh=_cfg(d, 'NMS_THRESH'),
-                                        use_cuda=True, device=device)
+                                        use_cuda=True, device=device, max_det=max_dets)   # best max_dets boxes per view: the tracker's capacity
             print("Person Detector : ", _cfg(d, 'NAME'), '(weights: %s)' % self.bbox_detector.weights)
         else:
             raise NotImplementedError('person detector %r' % _cfg(self.person_detector, 'NAME'))

@@ -179,3 +179,44 @@ def test_overlay_draws_confident_joints_only():
     assert out[int(pts[0, 0]), int(pts[0, 1])].any() and out[int(pts[8, 0]), int(pts[8, 1])].any()
     assert not out[int(pts[16, 0]) - 2:int(pts[16, 0]) + 3, int(pts[16, 1]) - 2:int(pts[16, 1]) + 3].any()
     assert tuple(out[int(pts[0, 0]), int(pts[0, 1])]) == (0, 0, 255)               # joint 0 = first rainbow hue (red), BGR
+
+
+@pytest.mark.gpu
+def test_testmodel_full_pipeline_with_detector(tmp_path, capsys):
+    """DETECT_MODEL: YOLOv3 + POSE_MODEL: HRPose + Iterative matcher on images from disk (random networks: this checks the
+    reference's loop structure, the wiring of every stage and the overlay / SAVE_IMAGE output, not accuracy)."""
+    import warnings
+    from PIL import Image
+    from pam import testmodel
+    seq = synth.make_sequence('S1', n_frames=16, seed=2)
+    rng = np.random.default_rng(0)
+    root = tmp_path / 'CampusSeq1'
+    for c in range(3):
+        os.makedirs(root / ('Camera%d' % c))
+        for t in range(16):
+            Image.fromarray(rng.integers(0, 256, (288, 360, 3), dtype=np.uint8)).save(root / ('Camera%d' % c) / ('%04d.png' % t))
+    with open(root / 'camera_parameter.pickle', 'wb') as f:
+        pickle.dump(seq['calib'], f)
+    cfg = GetConfig(os.path.join(pam.PKG_DIR, 'configs', 'CampusSeq1', 'model_configs.yaml'))
+    cfg.DATASET.ROOT = str(root); cfg.DATASET.DATA_FORMAT = '*.png'; cfg.DATASET.TEST_RANGE = [0, 16]
+    cfg.OUTPUT = str(tmp_path / 'out'); cfg.SAVE_IMAGE = True
+    cfg.PIPELINE_COMBINATION.DETECT_MODEL = 'YOLOv3'
+    cfg.DETECT_MODELS.YOLOV3.SCORE_THRESH = 0.6
+    seen = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        testmodel.test_ivclabpose_PersonTrack_Project3DPose(cfg, LoadFilenames(cfg.DATASET), on_frame=lambda fid, ts, res: seen.append((fid, res)))
+    out = capsys.readouterr().out
+    assert 'Person Detector :  YOLOv3' in out and 'Person Detect Processing time' in out and 'tracking fps' in out
+    assert [f for f, _ in seen] == list(range(16))
+    got = [r for _, r in seen if r is not None]
+    assert got, 'the random detector found no box in any frame'
+    for r in got:
+        assert len(r) == 9                                             # the reference's 9-tuple
+        camera_ids, pts, person_ids = r[0], r[1], r[2]
+        for cids, poses, pids in zip(camera_ids, pts, person_ids):
+            assert len(cids) == len(poses) == len(pids)
+            for p in poses:
+                assert np.asarray(p).shape == (17, 3)
+    saved = os.listdir(tmp_path / 'out' / 'CampusSeq1' / 'Images')
+    assert any(name.endswith('_0.jpg') for name in saved)
