@@ -5,7 +5,6 @@ The folded (conv + bias) PyTorch module of hrnet.py is walked once into packed w
 ``pam_upsample_add_nhwc_bf16`` per fuse-layer output that has coarser inputs.  Activations are NHWC bf16 torch tensors
 (channels-last); torch is used for memory and the stream only.  The whole forward is hipGraph-capturable."""
 import ctypes as C
-import os
 
 import torch
 import torch.nn as nn
@@ -159,9 +158,6 @@ class ConvEngine(object):
 
 
 class HipHRNet(ConvEngine):
-    # 'barrier': branch streams join/fork through the caller's stream after every stage (hipGraph-capturable);
-    # 'events': pairwise event dependencies (eager only: hipGraph capture of that pattern crashes in ROCm 7.2 at capture end)
-    sync_mode = os.environ.get('PAM_HRNET_SYNC', 'barrier')
     multi_stream = False
 
     def __init__(self, folded_model, device):
@@ -205,10 +201,15 @@ class HipHRNet(ConvEngine):
         return dict(branches=branches, fuse=fuse)
 
     # -- network ------------------------------------------------------------------------------------------------------
-    # Stream plan: branch b of every HR module, and fuse output b, always run on stream b (stream 0 = the caller's stream);
-    # cross-branch inputs are ordered by events, not by global joins, so a branch starts its next module as soon as ITS fuse
-    # output exists.  Every tensor of a forward is kept alive until the forward has been issued (self._keep), so the caching
-    # allocator can never hand a block that another stream still reads to a new tensor; all streams join at the end.
+    # Stream plan (stream 0 = the caller's stream; hipGraph-capturable -- pairwise event dependencies between the branch streams
+    # crashed capture on ROCm 7.2, so all cross-stream ordering is a join/fork through stream 0):
+    #   * stream b runs branch b of every HR module AND the fuse chains that start from branch b's output (strided-conv chains
+    #     down, 1x1 convs up);
+    #   * ONE join per module (a cross-stream join costs ~10 us of idle chip), then the sum of output i (one k_upsample_add over
+    #     all its terms) runs on stream i, where branch i of the next module continues without further sync;
+    #   * a join before every stage (the new branch's transition conv reads another stream's sum) and at the end.
+    # Every tensor of a forward is kept alive until the forward has been issued (self._keep), so the caching allocator can never
+    # hand a block that another stream still reads to a new tensor.
     def _stream(self, b):
         return None if (b == 0 or not self.multi_stream) else self.side[b - 1]
 
@@ -221,86 +222,39 @@ class HipHRNet(ConvEngine):
             for st in self.side:
                 st.wait_stream(cur)
 
-    def _record(self, b):
-        if not self.multi_stream or self.sync_mode == 'barrier':
-            return None
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device) if b == 0 else self.side[b - 1])
-        return ev
-
-    def _wait(self, b, ev):
-        if ev is not None:
-            (torch.cuda.current_stream(self.device) if b == 0 else self.side[b - 1]).wait_event(ev)
-
-    def _hr_module(self, mod, xs, ready):
-        """xs[b]: tensor or ('lazy', op, src_tensor, src_event) for a branch created by a transition; ready[b]: event."""
-        nb = len(mod['branches'])
-        xs, ready = list(xs), list(ready)
+    def _hr_module(self, mod, xs):
+        """xs[b]: tensor, or ('lazy', transition op, source tensor) for a branch this stage creates."""
+        xs = list(xs)
         fuse = mod['fuse']
-        if self.sync_mode == 'barrier' and self.multi_stream:
-            # Cross-stream joins cost ~10 us of idle chip each, so a module has exactly one: stream b runs branch b AND the
-            # fuse chains that start from branch b's output (strided-conv chains down, 1x1 convs up); after the join, the
-            # sum of output i runs on stream i, where branch i of the next module continues without any further sync.
-            terms = [dict() for _ in fuse]
-            for b, blocks in enumerate(mod['branches']):
-                with torch.cuda.stream(self._stream(b)):
-                    x = xs[b]
-                    if isinstance(x, tuple):                          # transition conv runs on the new branch's own stream
-                        x = self.conv(x[1], x[2], relu=True)
-                    for c1, c2 in blocks:
-                        y = self.conv(c1, x, relu=True)
-                        x = self.conv(c2, y, res=x, relu=True)
-                    xs[b] = x
-                    for i, row in enumerate(fuse):
-                        f = row[b] if b < len(row) else None
-                        if f is None:
-                            continue
-                        if f[0] == 'up':
-                            terms[i][b] = (self.conv(f[1], x), f[2])
-                        else:
-                            t = x
-                            for k, op in enumerate(f[1]):
-                                t = self.conv(op, t, relu=(k < len(f[1]) - 1))
-                            terms[i][b] = (t, 0)
-            self._barrier()
-            out = [None] * len(fuse)
-            for i in range(len(fuse)):
-                with torch.cuda.stream(self._stream(i)):
-                    tl = [terms[i][j] for j in sorted(terms[i])]
-                    out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])
-            return out, [None] * len(fuse)
+        terms = [dict() for _ in fuse]
         for b, blocks in enumerate(mod['branches']):
             with torch.cuda.stream(self._stream(b)):
                 x = xs[b]
                 if isinstance(x, tuple):                              # transition conv runs on the new branch's own stream
-                    _, op, src, ev = x
-                    self._wait(b, ev)
-                    x = self.conv(op, src, relu=True)
+                    x = self.conv(x[1], x[2], relu=True)
                 for c1, c2 in blocks:
                     y = self.conv(c1, x, relu=True)
                     x = self.conv(c2, y, res=x, relu=True)
                 xs[b] = x
-                ready[b] = self._record(b)
-        # fuse: out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)); all terms of output i on
-        # stream i, ONE k_upsample_add per output (shift 0 for the same-resolution down terms)
-        out, oready = [None] * len(fuse), [None] * len(fuse)
-        for i, row in enumerate(fuse):
-            with torch.cuda.stream(self._stream(i)):
-                terms, shifts = [], []
-                for j, f in enumerate(row):
+                for i, row in enumerate(fuse):
+                    f = row[b] if b < len(row) else None
                     if f is None:
                         continue
-                    self._wait(i, ready[j])
                     if f[0] == 'up':
-                        terms.append(self.conv(f[1], xs[j])); shifts.append(f[2])
+                        terms[i][b] = (self.conv(f[1], x), f[2])
                     else:
-                        t = xs[j]
+                        t = x
                         for k, op in enumerate(f[1]):
                             t = self.conv(op, t, relu=(k < len(f[1]) - 1))
-                        terms.append(t); shifts.append(0)
-                out[i] = self.upsample_add(xs[i], terms, shifts, relu=True) if terms else torch.relu(xs[i])
-                oready[i] = self._record(i)
-        return out, oready
+                        terms[i][b] = (t, 0)
+        self._barrier()
+        # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order
+        out = [None] * len(fuse)
+        for i in range(len(fuse)):
+            with torch.cuda.stream(self._stream(i)):
+                tl = [terms[i][j] for j in sorted(terms[i])]
+                out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])
+        return out
 
     def features(self, x8):
         """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
@@ -308,45 +262,27 @@ class HipHRNet(ConvEngine):
         return self._features(x8)
 
     def _features(self, x8):
-        ms = self.multi_stream
-        cur = torch.cuda.current_stream(self.device) if ms else None
-        if ms:
-            for st in self.side:
-                st.wait_stream(cur)
         x = self.conv(self.conv1, x8, relu=True)
         x = self.conv(self.conv2, x, relu=True)
         for b in self.layer1:
-            if b['down'] is not None and ms and self.sync_mode == 'events':   # 1x1 skip projection beside the main path
-                ev0 = self._record(0)
-                with torch.cuda.stream(self._stream(1)):
-                    self._wait(1, ev0)
-                    r = self.conv(b['down'], x)
-                    evr = self._record(1)
-            else:
-                r = x if b['down'] is None else self.conv(b['down'], x)
-                evr = None
+            r = x if b['down'] is None else self.conv(b['down'], x)
             y = self.conv(b['c1'], x, relu=True)
             y = self.conv(b['c2'], y, relu=True)
-            self._wait(0, evr)
             x = self.conv(b['c3'], y, res=r, relu=True)
-        ev = self._record(0)
-        if self.sync_mode == 'barrier':
-            self._barrier()                                           # branch streams must see layer1's output
-        xs = [('lazy', self.t1[0], x, ev), ('lazy', self.t1[1], x, ev)]
-        ready = [ev, ev]
+        self._barrier()                                               # branch streams must see layer1's output
+        xs = [('lazy', self.t1[0], x), ('lazy', self.t1[1], x)]
         for m in self.stage2:
-            xs, ready = self._hr_module(m, xs, ready)
-        if self.sync_mode == 'barrier':
-            self._barrier()                                           # the new branch's stream reads the last sum of stage 2
-        xs = xs + [('lazy', self.t2, xs[-1], ready[-1])]; ready = ready + [ready[-1]]
+            xs = self._hr_module(m, xs)
+        self._barrier()                                               # the new branch's stream reads the last sum of stage 2
+        xs = xs + [('lazy', self.t2, xs[-1])]
         for m in self.stage3:
-            xs, ready = self._hr_module(m, xs, ready)
-        if self.sync_mode == 'barrier':
-            self._barrier()
-        xs = xs + [('lazy', self.t3, xs[-1], ready[-1])]; ready = ready + [ready[-1]]
+            xs = self._hr_module(m, xs)
+        self._barrier()
+        xs = xs + [('lazy', self.t3, xs[-1])]
         for m in self.stage4:
-            xs, ready = self._hr_module(m, xs, ready)
-        if ms:
+            xs = self._hr_module(m, xs)
+        if self.multi_stream:                                         # final join only (no re-fork: capture must end with no forked stream)
+            cur = torch.cuda.current_stream(self.device)
             for st in self.side:
                 cur.wait_stream(st)
         return xs[0]
