@@ -7,10 +7,8 @@ The folded (conv + bias) PyTorch module of hrnet.py is walked once into packed w
 import ctypes as C
 
 import torch
-import torch.nn as nn
 
 from . import _lib
-from . import hrnet as H
 
 
 class PackedConv(object):

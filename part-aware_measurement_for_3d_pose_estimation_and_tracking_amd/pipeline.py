@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .distributed import CropGather, ViewGather, view_partition
+from .distributed import CropGather, ViewGather
 from .hrnet import HRNetPose
 
 NUM_JOINTS = 17
