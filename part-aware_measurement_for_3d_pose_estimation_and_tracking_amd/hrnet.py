@@ -231,7 +231,7 @@ class HRNetPose(object):
     ``predict(person_bbox_list, batch_size, conf_threshold) -> dump_results`` (ivclabpose.py:131-132,210)."""
 
     def __init__(self, c, nof_joints, checkpoint_path, model_name='HRNet', resolution=(384, 288), hrpose_args=None,
-                 device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16, backend='hip'):
+                 device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16, backend='hip', graph_bucket=4):
         assert model_name == 'HRNet' and int(nof_joints) == 17
         if not torch.cuda.is_available():
             raise RuntimeError('HRNetPose needs a GPU (the preprocessing / decode kernels are HIP only; no CPU fallback)')
@@ -262,6 +262,10 @@ class HRNetPose(object):
             assert backend == 'miopen', backend
             self.model = model.to(self.device).to(dtype).to(memory_format=torch.channels_last).eval()
         self.use_graph = use_graph
+        # predict() pads a batch to the next multiple of graph_bucket crops (repeating its last box; the padded rows are not
+        # decoded): a sequence whose person count wanders then replays a handful of captured graphs instead of capturing one
+        # per count (a capture is a multi-100-ms stall); 1 = exact batch sizes
+        self.graph_bucket = max(1, int(graph_bucket)) if use_graph else 1
         self._graphs = {}
         self._pool = None
         self.stream = torch.cuda.current_stream(self.device)
@@ -364,10 +368,15 @@ class HRNetPose(object):
         kp = torch.empty((n, 17, 3), dtype=torch.float32, device=self.device)
         for s in range(0, n, batch_size):
             e = min(n, s + batch_size)
-            x = self.input_buffer(e - s)
-            self.preprocess(ptrs, fh, fw, view_of[s:e], bx[s:e], x)
+            m = e - s
+            mp = min(batch_size, (m + self.graph_bucket - 1) // self.graph_bucket * self.graph_bucket) if batch_size >= self.graph_bucket else m
+            vo, bb = view_of[s:e], bx[s:e]
+            if mp > m:                                   # pad with copies of the last crop
+                vo = torch.cat([vo, vo[-1:].expand(mp - m)]); bb = torch.cat([bb, bb[-1:].expand(mp - m, 4)])
+            x = self.input_buffer(mp)
+            self.preprocess(ptrs, fh, fw, vo.contiguous(), bb.contiguous(), x)
             hm = self.heatmaps(x)
-            self.decode(hm, view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
+            self.decode(hm[:m], view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
         kp_h = kp.cpu().numpy()
         for i in range(n):
             k = kp_h[i].astype(np.float64)

@@ -191,5 +191,12 @@ def test_predict_dump_format_and_facade_end_to_end():
     for a, b in zip(dump, dump2):
         for ia, ib in zip(a, b):
             assert ia['keypoints'] == ib['keypoints']
+    assert model.pose_model.graph_bucket == 4 and 4 in model.pose_model._graphs and 3 not in model.pose_model._graphs   # 3 crops ran padded to 4
+    model.pose_model.graph_bucket = 1                                                         # exact batch sizes: same result
+    dump3 = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
+    assert 3 in model.pose_model._graphs
+    for a, b in zip(dump, dump3):
+        for ia, ib in zip(a, b):
+            assert ia['keypoints'] == ib['keypoints']
     out = model.PersonTrack_Project3DPose(0, pbl, dump, 'SVD')
     assert len(out) == 9 and len(out[5]) == 0          # nothing confirmed on the first frame
