@@ -148,6 +148,11 @@ int pam_op_hyp_cost(PamHandle* h, int n_members, const int32_t* cids, const doub
  * pam_decode_heatmaps: heat-maps (n, hm_h, hm_w, 17) float32 NHWC or (n,17,hm_h,hm_w) NCHW (nchw flag) -> per person
  * hard arg-max per joint mapped through the box; writes float64 rows (y, x, score) into the tracker's det buffer
  * slot (view_of[i], slot_of[i]).  All pointers are device pointers; asynchronous on `stream`. */
+/* final 1x1 convolution of the pose network (`final_layer` of the HRNet module inside HRNetPose.predict): features NHWC bf16
+ * (n_pix pixels x C channels, C % 8 == 0) -> heat-maps NHWC float32 (n_pix x J, J = 17); w [J][C] float32, bias [J] or NULL;
+ * float32 FMA chain over the channels in order, starting from the bias. */
+int pam_head_heatmaps(void* stream, int n_pix, const void* feat_bf16, int C, const float* w, const float* bias, int J,
+                      float* out);
 int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames /*dev array of n_views frame ptrs*/,
                          int frame_h, int frame_w, const int32_t* dev_view_of, const float* dev_boxes,
                          int out_h, int out_w, int out_c /*3, or 8 = RGB + 5 zero channels*/, void* dev_out_bf16);

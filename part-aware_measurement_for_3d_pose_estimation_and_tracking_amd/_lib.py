@@ -66,6 +66,7 @@ _SIGS = {
     'pam_conv3x3_slab': (_I, [_I, _I, _I, _I]),
     'pam_conv_debug_stamps': (_I, [_P]),
     'pam_upsample_add_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
+    'pam_head_heatmaps': (_I, [_P, _I, _P, _I, _P, _P, _I, _P]),
     'pam_resize_frames': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'pam_upsample_concat_nhwc_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'pam_yolo_detect': (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, C.c_float, _I, _I, _I, _P, _P]),

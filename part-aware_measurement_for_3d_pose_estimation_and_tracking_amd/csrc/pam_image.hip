@@ -146,6 +146,57 @@ __global__ __launch_bounds__(256) void k_decode_nchw(int n, const float* __restr
     }
 }
 
+// ---- final 1x1 convolution of the pose network: features NHWC bf16 (C channels) -> heat-maps NHWC float32 (J maps) ----------------
+// One thread per pixel: 16-byte feature loads, the J x C float32 weights broadcast from LDS, J running sums in registers
+// (float32 FMA chain over the channels in order, bias first); the workgroup's 256 x J outputs are contiguous in memory and
+// leave through LDS as full 16-byte stores.  Streaming: C*2 bytes in, J*4 bytes out per pixel.
+#define HEAD_T 256
+template <int JN>
+__global__ __launch_bounds__(HEAD_T) void k_head(int npix, const uint16_t* __restrict__ feat, int C, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];       // [JN*C] weights, then [HEAD_T*JN] output staging
+    float* ws = hsm; float* os = hsm + JN * C;
+    for (int i = threadIdx.x; i < JN * C; i += HEAD_T) ws[i] = w[i];
+    __syncthreads();
+    const int px = blockIdx.x * HEAD_T + threadIdx.x;
+    float acc[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[j] = bias ? bias[j] : 0.0f;
+    if (px < npix) {
+        const uint16_t* f = feat + (size_t)px * C;
+        for (int c8 = 0; c8 < C; c8 += 8) {
+            const uint4 v = *(const uint4*)(f + c8);
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x[2 * k] = __uint_as_float(d[k] << 16); x[2 * k + 1] = __uint_as_float(d[k] & 0xffff0000u); }
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[j] = fmaf(x[k], ws[j * C + c8 + k], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < JN; ++j) os[threadIdx.x * JN + j] = acc[j];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * HEAD_T * JN;             // this workgroup's outputs: [base, base + HEAD_T*JN) floats
+    const size_t total = (size_t)npix * JN;
+    for (int i = threadIdx.x * 4; i < HEAD_T * JN; i += HEAD_T * 4) {
+        if (base + i + 3 < total) *(float4*)(out + base + i) = *(const float4*)(os + i);
+        else for (int k = 0; k < 4; ++k) if (base + i + k < total) out[base + i + k] = os[i + k];
+    }
+}
+
+extern "C" int pam_head_heatmaps(void* stream, int n_pix, const void* feat_bf16, int C, const float* w, const float* bias,
+                                 int J_, float* out) {
+    if (n_pix < 0 || !feat_bf16 || !w || !out || C <= 0 || C % 8 != 0 || J_ != PAM_J || (HEAD_T * J_) % 4 != 0) return PAM_E_ARG;
+    if (n_pix == 0) return PAM_OK;
+    const size_t lds = ((size_t)J_ * C + (size_t)HEAD_T * J_) * sizeof(float);
+    hipLaunchKernelGGL((k_head<PAM_J>), dim3((n_pix + HEAD_T - 1) / HEAD_T), dim3(HEAD_T), lds, (hipStream_t)stream, n_pix,
+                       (const uint16_t*)feat_bf16, C, w, bias, out);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
 extern "C" int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames, int frame_h, int frame_w,
                                     const int32_t* dev_view_of, const float* dev_boxes, int out_h, int out_w,
                                     int out_c, void* dev_out_bf16) {

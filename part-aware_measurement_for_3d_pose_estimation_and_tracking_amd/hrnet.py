@@ -250,6 +250,8 @@ class HRNetPose(object):
             self.weights = 'random(seed=%d)' % seed
         model = fold_batchnorm(model)
         self.head = model.final_layer.to(self.device).float()           # 1x1 head + decode stay float32
+        self.head_w = self.head.weight.detach().reshape(int(nof_joints), -1).contiguous()     # [17][48] for k_head
+        self.head_b = self.head.bias.detach().contiguous()
         model.final_layer = nn.Identity()
         self.backend = backend
         self.in_channels = 3
@@ -272,8 +274,17 @@ class HRNetPose(object):
 
     # -- conv stack (PyTorch-ROCm; hipGraph replay per batch size) -------------------------------------------------
     def _forward(self, x):
-        f = self.hip.features(x) if self.backend == 'hip' else self.model.features(x)
-        return self.head(f.float())
+        if self.backend != 'hip':
+            return self.head(self.model.features(x).float())
+        f = self.hip.features(x)                                        # (N, 48, h, w) channels-last bf16
+        n, c, h, w = f.shape
+        hm = torch.empty((n, self.head_w.shape[0], h, w), dtype=torch.float32, device=f.device, memory_format=torch.channels_last)
+        rc = self.lib.pam_head_heatmaps(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), n * h * w,
+                                        C.c_void_p(f.data_ptr()), c, C.c_void_p(self.head_w.data_ptr()),
+                                        C.c_void_p(self.head_b.data_ptr()), self.head_w.shape[0], C.c_void_p(hm.data_ptr()))
+        if rc != 0:
+            raise _lib.PamError('pam_head_heatmaps failed: %d' % rc)
+        return hm
 
     def heatmaps(self, x):
         """x: (N,3,H,W) channels-last bf16 on the device -> (N,17,H/4,W/4) float32 (channels-last memory)."""

@@ -200,3 +200,21 @@ def test_predict_dump_format_and_facade_end_to_end():
             assert ia['keypoints'] == ib['keypoints']
     out = model.PersonTrack_Project3DPose(0, pbl, dump, 'SVD')
     assert len(out) == 9 and len(out[5]) == 0          # nothing confirmed on the first frame
+
+
+def test_head_kernel_vs_torch_fp32():
+    """pam_head_heatmaps (final 1x1 conv, float32 FMA over bf16 features) against F.conv2d in float32, incl. a ragged last workgroup."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from pam import _lib
+    g = torch.Generator().manual_seed(4)
+    for (n, h, w) in [(3, 96, 72), (1, 7, 5)]:
+        f = torch.randn((n, 48, h, w), generator=g).to(torch.bfloat16).to('cuda:0').contiguous(memory_format=torch.channels_last)
+        wt = (torch.randn((17, 48), generator=g) * 0.2).to('cuda:0'); b = torch.randn(17, generator=g).to('cuda:0')
+        out = torch.full((n, 17, h, w), 9.0, dtype=torch.float32, device='cuda:0').contiguous(memory_format=torch.channels_last)
+        rc = _lib.load().pam_head_heatmaps(None, n * h * w, C.c_void_p(f.data_ptr()), 48, C.c_void_p(wt.data_ptr()), C.c_void_p(b.data_ptr()),
+                                           17, C.c_void_p(out.data_ptr()))
+        assert rc == 0
+        ref = F.conv2d(f.float(), wt.reshape(17, 48, 1, 1), b)
+        torch.cuda.synchronize()
+        assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-5
