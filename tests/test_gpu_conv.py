@@ -21,6 +21,8 @@ CASES = [
     (2, 24, 18, 64, 64, 3, 1, True, True),        # layer1 bottleneck 3x3 (64-wide N tiles)
     (20, 96, 72, 48, 48, 3, 1, True, True),       # full-size branch-0 layer
     (2, 25, 18, 48, 48, 3, 1, True, True),        # ragged last row tile (25 = 12 + 12 + 1)
+    (180, 25, 18, 48, 48, 3, 1, True, True),      # 540 tiles on 512 persistent workgroups, ragged tiles among the second ones
+    (50, 96, 72, 48, 48, 3, 1, True, True),       # 1600 tiles: every persistent workgroup walks 3-4 tiles
     (1, 7, 5, 96, 96, 3, 1, True, True),          # tiny image: one 2-wave workgroup per slab
     (3, 31, 72, 48, 96, 3, 1, False, True),       # ragged, wide rows, Cout != Cin
     (2, 9, 12, 384, 192, 3, 1, True, False),      # 64-channel chunks, narrow slabs
