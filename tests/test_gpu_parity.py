@@ -191,3 +191,39 @@ def test_batched_scenes_match_single(lib):
     for hs in singles:
         hs.close()
     hb.close()
+
+
+@pytest.mark.parametrize('size,seed,kw', [
+    ('S1', 21, dict(occlusion_every=3, empty_view_every=5, birth_death_frame=30)),
+    ('S2', 22, dict(occlusion_every=4, empty_view_every=9, birth_death_frame=45)),
+    ('S2', 23, dict(occlusion_every=2, empty_view_every=4, birth_death_frame=20, blank_frames=(33, 34, 60))),
+    ('S3', 24, dict(occlusion_every=3, empty_view_every=7, birth_death_frame=40)),
+])
+def test_facade_vs_oracle_on_fresh_stress_sequences(size, seed, kw):
+    """Sequences that are NOT among the goldens (other seeds, much denser occlusions / empty views / births and deaths) through
+    the drop-in facade vs the pinned oracle: ids, per-view assignments and view sets identical, 3D <= 1e-6 m, every frame."""
+    from pam import synth
+    from pam.ivclabpose import ivclabpose
+    from oracle import cpu_ref as O
+    meta = synth.SIZES[size]
+    seq = synth.make_sequence(size, n_frames=120, seed=seed, **kw)
+    cfg = dict(synth.MATCHER_CFG[synth.SIZE_TO_DATASET[size]]); conf = cfg.pop('CONF_THRESHOLD')
+    dev = ivclabpose({'NAME': ''}, None, dict(cfg, NAME='Iterative'), conf)
+    cams = dev.GetCameraParameters(seq['calib'], meta['h'], meta['w'])
+    ref = O.OracleIvclabpose(cfg, conf)
+    ref.GetCameraParameters(seq['calib'], F=np.stack([c.F for c in cams]))
+    n_out = 0
+    for t, views in enumerate(seq['frames']):
+        pbl, dr = synth.to_dump_results(views)
+        if not any(len(v) for v in dr):
+            continue                                          # the drivers skip frames without any pose (testmodel.py:66)
+        a = dev.PersonTrack_Project3DPose(t, pbl, dr, 'SVD')
+        b = ref.PersonTrack_Project3DPose(t, pbl, dr, 'SVD')
+        assert list(a[5]) == list(b[5]), (t, a[5], b[5])                                   # emitted track ids
+        assert [list(map(int, c)) for c in a[0]] == [list(map(int, c)) for c in b[0]], t   # camera ids per track
+        assert [list(map(int, c)) for c in a[2]] == [list(map(int, c)) for c in b[2]], t   # person (detection) ids per track
+        assert a[4] == b[4], t                                                             # views per joint
+        if len(a[5]):
+            assert np.abs(np.asarray(a[3]) - np.asarray(b[3])).max() < 1e-6, t
+            n_out += len(a[5])
+    assert n_out > 100
