@@ -176,12 +176,21 @@ int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw
 int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                          const void* residual, void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
                          int stride, int pad, int relu, int tile_cfg);
+/* the same with channel-sliced operands, for the merged fuse-layer convolutions: the input pixels are in_cstride channels apart
+ * (`in` points at the first of the Cin channels read; 0 = Cin), and the activation applies only to output channels >= relu_from
+ * (multiple of 16; 0 = all).  Either option selects the generic kernel. */
+int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
+                            const void* residual, void* out, int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                            int stride, int pad, int relu, int tile_cfg, int in_cstride, int relu_from);
 /* output channels per workgroup slab (BN) that k_conv3x3 uses for a layer shape; weight images must be packed with it */
 int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
 /* diagnostic builds only: device buffer (64 x uint64 per workgroup) for k_conv3x3's s_memtime stamps, used when tile_cfg = 100 + 64 */
 int pam_conv_debug_stamps(void* dev_buf);
 int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, const void* const* terms,
                                const int32_t* shifts, void* out, int N, int H, int W, int C, int relu);
+/* the same with terms that are channel slices of wider tensors: term_cstrides[t] = channels between pixels of term t (NULL / 0 = C) */
+int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int n_terms, const void* const* terms, const int32_t* shifts,
+                                  const int32_t* term_cstrides, void* out, int N, int H, int W, int C, int relu);
 
 /* ---- person detector side (ivclabpose.py:116-120 constructs backend.YOLOv3, :183-204 PersonDetect calls it).
  * The backend is absent from the reference tree; these follow the public Darknet YOLOv3 definition (parity unpinned).

@@ -28,6 +28,8 @@ __device__ __forceinline__ float epi_act(float v, float r, int act) {
 struct ConvArgs {
     const uint16_t* in; const uint16_t* w; const float* bias; const uint16_t* res; uint16_t* out;
     int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, relu, Ktot, Kpad, M;
+    int in_cs;        // channel stride of the input pixels (= Cin unless the input is a channel slice of a wider tensor)
+    int relu_from;    // the activation applies to output channels >= relu_from (0 = all); multiple of 16
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int kq = tid & 7;
-    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * a.Cin * 2), 0x00020000);
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * a.in_cs * 2), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Cout * a.Kpad * 2), 0x00020000);
 
     // per-thread output-pixel rows of the A tile (fixed over the K loop): byte offset of the window corner and a
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
             const int hw = a.Ho * a.Wo;
             const int n = m / hw, r = m - n * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            rowoff[i] = (unsigned)((((long)n * a.H + iy0) * a.W + ix0) * a.Cin * 2);   // may wrap; only used with valid taps
+            rowoff[i] = (unsigned)((((long)n * a.H + iy0) * a.W + ix0) * a.in_cs * 2); // may wrap; only used with valid taps
             unsigned mk = 0;
             for (int ky = 0; ky < a.KH; ++ky)
                 for (int kx = 0; kx < a.KW; ++kx)
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
     u32x4 areg[APT], breg[BPT];
     auto load_chunk = [&]() {
         const int ky = kc_tap / a.KW, kx = kc_tap - ky * a.KW;
-        const unsigned tapoff = (unsigned)(((ky * a.W + kx) * a.Cin + kc_c) * 2);
+        const unsigned tapoff = (unsigned)(((ky * a.W + kx) * a.in_cs + kc_c) * 2);
         const unsigned tbit = (kc_tap < a.KH * a.KW) ? (1u << kc_tap) : 0u;
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
@@ -232,15 +234,16 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
                     rr[0] = __builtin_bit_cast(float, rres[2 * j] << 16); rr[1] = __builtin_bit_cast(float, rres[2 * j] & 0xffff0000u);
                     rr[2] = __builtin_bit_cast(float, rres[2 * j + 1] << 16); rr[3] = __builtin_bit_cast(float, rres[2 * j + 1] & 0xffff0000u);
                 }
+                const bool act_on = cw0 + g * 4 * NTW + j * 4 >= a.relu_from;   // merged fuse-layer convs: only the upper channels
                 if constexpr (GEN) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], rr[r], a.relu);
+                    for (int r = 0; r < 4; ++r) v[r] = epi_act(v[r], rr[r], act_on ? a.relu : (a.relu & 4));
                     ov[2 * j] = pack_bf16x2(v[0], v[1]); ov[2 * j + 1] = pack_bf16x2(v[2], v[3]);
                 } else {                                // HRNet's codes 0 / 1; ReLU as a packed int16 max on the bf16 pairs
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += rr[r];
                     ov[2 * j] = pack_bf16x2(v[0], v[1]); ov[2 * j + 1] = pack_bf16x2(v[2], v[3]);
-                    if (a.relu) {
+                    if (a.relu && act_on) {
                         ov[2 * j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j]), (s16x2){0, 0}));
                         ov[2 * j + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j + 1]), (s16x2){0, 0}));
                     }
@@ -696,9 +699,21 @@ __global__ __launch_bounds__(256) void k_conv_stem(StemArgs a) {
     }
 }
 
+extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
+                                       const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
+                                       int KH, int KW, int stride, int pad, int relu, int tile_cfg, int in_cstride, int relu_from);
 extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                                     const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
                                     int KH, int KW, int stride, int pad, int relu, int tile_cfg) {
+    return pam_conv2d_nhwc_bf16_ex(stream, in, w_packed, w_img, bias, residual, out, N, H, W, Cin, Cout, KH, KW, stride, pad, relu,
+                                   tile_cfg, Cin, 0);
+}
+extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
+                                       const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
+                                       int KH, int KW, int stride, int pad, int relu, int tile_cfg, int in_cstride, int relu_from) {
+    if (in_cstride <= 0) in_cstride = Cin;
+    if (in_cstride < Cin || in_cstride % 8 != 0 || relu_from < 0 || relu_from % 16 != 0) return PAM_E_ARG;
+    if (in_cstride != Cin || relu_from != 0) w_img = nullptr;          // sliced input / partial activation: generic kernel only
     const bool stem32 = w_img && Cin == 8 && Cout == 32 && KH == 3 && KW == 3 && pad == 1 && !residual && tile_cfg < 0 && stride <= 2;
     if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || (Cout % 48 != 0 && Cout % 64 != 0 && !stem32) ||
         KH < 1 || KW < 1 || KH > 3 || KW > 3 || stride < 1)
@@ -707,6 +722,7 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
     a.in = (const uint16_t*)in; a.w = (const uint16_t*)w_packed; a.bias = bias; a.res = (const uint16_t*)residual;
     a.out = (uint16_t*)out;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.relu = relu;
+    a.in_cs = in_cstride; a.relu_from = relu_from;
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
     a.Ktot = KH * KW * Cin; a.Kpad = (a.Ktot + KC - 1) / KC * KC; a.M = N * a.Ho * a.Wo;
     if (H >= 32768 || W >= 32768) return PAM_E_ARG;
@@ -773,7 +789,7 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
 }
 
 // out[n,y,x,c] = [relu](base[n,y,x,c] + sum_t term_t[n, y >> sh_t, x >> sh_t, c]); 8 channels (16 B) per thread
-struct UpArgs { const uint16_t* base; const uint16_t* term[3]; int sh[3]; int nterms; uint16_t* out; int N, H, W, C, relu; };
+struct UpArgs { const uint16_t* base; const uint16_t* term[3]; int sh[3]; int tcs[3]; int nterms; uint16_t* out; int N, H, W, C, relu; };
 __global__ __launch_bounds__(256) void k_upsample_add(UpArgs a) {
     const unsigned C8 = (unsigned)a.C >> 3, total = (unsigned)a.N * a.H * a.W * C8;       // host checks total < 2^31: 32-bit index math
     for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -787,7 +803,7 @@ __global__ __launch_bounds__(256) void k_upsample_add(UpArgs a) {
             q[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
             if (t < a.nterms) {
                 const unsigned hs = (unsigned)a.H >> a.sh[t], ws = (unsigned)a.W >> a.sh[t];
-                q[t] = *(const bf16x8*)(a.term[t] + ((size_t)(n * hs + (y >> a.sh[t])) * ws + (x >> a.sh[t])) * a.C + c8 * 8);
+                q[t] = *(const bf16x8*)(a.term[t] + ((size_t)(n * hs + (y >> a.sh[t])) * ws + (x >> a.sh[t])) * a.tcs[t] + c8 * 8);
             }
         }
         float v[8];
@@ -806,12 +822,22 @@ __global__ __launch_bounds__(256) void k_upsample_add(UpArgs a) {
     }
 }
 
+extern "C" int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int n_terms, const void* const* terms,
+                                             const int32_t* shifts, const int32_t* term_cstrides, void* out, int N, int H, int W, int C, int relu);
 extern "C" int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, const void* const* terms,
                                           const int32_t* shifts, void* out, int N, int H, int W, int C, int relu) {
+    return pam_upsample_add_nhwc_bf16_ex(stream, base, n_terms, terms, shifts, nullptr, out, N, H, W, C, relu);
+}
+extern "C" int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int n_terms, const void* const* terms,
+                                             const int32_t* shifts, const int32_t* term_cstrides, void* out, int N, int H, int W, int C, int relu) {
     if (!base || !out || n_terms < 0 || n_terms > 3 || C % 8 != 0 || (size_t)N * H * W * (C / 8) >= (1ull << 31)) return PAM_E_ARG;
     UpArgs a;
     a.base = (const uint16_t*)base; a.out = (uint16_t*)out; a.nterms = n_terms;
-    for (int t = 0; t < 3; ++t) { a.term[t] = t < n_terms ? (const uint16_t*)terms[t] : nullptr; a.sh[t] = t < n_terms ? shifts[t] : 0; }
+    for (int t = 0; t < 3; ++t) {
+        a.term[t] = t < n_terms ? (const uint16_t*)terms[t] : nullptr; a.sh[t] = t < n_terms ? shifts[t] : 0;
+        a.tcs[t] = (t < n_terms && term_cstrides && term_cstrides[t] > 0) ? term_cstrides[t] : C;
+        if (a.tcs[t] < C || a.tcs[t] % 8 != 0) return PAM_E_ARG;
+    }
     a.N = N; a.H = H; a.W = W; a.C = C; a.relu = relu;
     const size_t total = (size_t)N * H * W * (C / 8);
     int blocks = (int)((total + 255) / 256);

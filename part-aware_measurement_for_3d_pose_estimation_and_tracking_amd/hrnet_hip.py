@@ -7,6 +7,7 @@ The folded (conv + bias) PyTorch module of hrnet.py is walked once into packed w
 import ctypes as C
 
 import torch
+import torch.nn as nn
 
 from . import _lib
 
@@ -55,6 +56,19 @@ class PackedConv(object):
                     frag[j, ky, sel] = w[ch[sel], :, ky, kx[sel]]
             self._stem = frag.to(torch.bfloat16).to(device).contiguous()
 
+    @staticmethod
+    def merged(convs, device):
+        """One convolution computing several same-shaped convolutions of the same input: weights / biases concatenated along
+        the output channels, in the given order."""
+        c0 = convs[0]
+        assert all(c.kernel_size == c0.kernel_size and c.stride == c0.stride and c.padding == c0.padding and
+                   c.in_channels == c0.in_channels for c in convs)
+        m = nn.Conv2d(c0.in_channels, sum(c.out_channels for c in convs), c0.kernel_size, c0.stride, c0.padding, bias=True)
+        with torch.no_grad():
+            m.weight.copy_(torch.cat([c.weight.detach().float() for c in convs], 0))
+            m.bias.copy_(torch.cat([(c.bias.detach().float() if c.bias is not None else torch.zeros(c.out_channels)) for c in convs]))
+        return PackedConv(m, device)
+
     def image(self, h, w):
         """Weight image [cout/BN][cin/CK][BN][pitch/2] bf16 (row = 9 taps x CK channels + pad) for this layer at input h x w."""
         if self._stem is not None:
@@ -88,10 +102,12 @@ class ConvEngine(object):
     _keep = None
     ACT = {None: 0, False: 0, True: 1, 'linear': 0, 'relu': 1, 'leaky': 2}
 
-    def conv(self, op, x, res=None, relu=False, res_after_act=False):
-        """relu: False/True, or 'linear' | 'relu' | 'leaky' (slope 0.1); res_after_act: out = act(conv + b) + res (Darknet shortcut)."""
+    def conv(self, op, x, res=None, relu=False, res_after_act=False, relu_from=0):
+        """relu: False/True, or 'linear' | 'relu' | 'leaky' (slope 0.1); res_after_act: out = act(conv + b) + res (Darknet shortcut).
+        x may be a channel slice of a wider channels-last tensor; relu_from: the activation applies to channels >= relu_from."""
         n, cin, h, w = x.shape
-        assert cin == op.cin and x.is_contiguous(memory_format=torch.channels_last), (x.shape, op.cin)
+        in_cs = cin if x.device.type == 'meta' else x.stride(3)          # channels between neighbouring pixels
+        assert cin == op.cin and (x.device.type == 'meta' or (x.stride(1) == 1 and x.stride(2) == w * in_cs and x.stride(0) == h * w * in_cs)), (x.shape, op.cin)
         ho = (h + 2 * op.pad - op.kh) // op.stride + 1
         wo = (w + 2 * op.pad - op.kw) // op.stride + 1
         y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
@@ -104,13 +120,13 @@ class ConvEngine(object):
         if x.device.type == 'meta':
             return y
         act = self.ACT[relu] | (4 if (res_after_act and res is not None) else 0)
-        wimg = op.image(h, w)
+        wimg = op.image(h, w) if (in_cs == cin and relu_from == 0) else None
         st = torch.cuda.current_stream(x.device).cuda_stream
-        rc = self.lib.pam_conv2d_nhwc_bf16(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
-                                           C.c_void_p(wimg.data_ptr()) if wimg is not None else None,
-                                           C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
-                                           C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad,
-                                           act, self.tile_cfg)
+        rc = self.lib.pam_conv2d_nhwc_bf16_ex(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
+                                              C.c_void_p(wimg.data_ptr()) if wimg is not None else None,
+                                              C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
+                                              C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad,
+                                              act, self.tile_cfg, in_cs, relu_from)
         if rc != 0:
             raise _lib.PamError('pam_conv2d_nhwc_bf16 failed (%d) for %s' % (rc, (x.shape, op.cout, op.kh, op.stride)))
         return y
@@ -128,8 +144,9 @@ class ConvEngine(object):
         st = torch.cuda.current_stream(base.device).cuda_stream
         ptrs = (C.c_void_p * 3)(*[C.c_void_p(t.data_ptr()) for t in terms] + [None] * (3 - len(terms)))
         sh = (C.c_int32 * 3)(*(list(shifts) + [0] * (3 - len(shifts))))
-        rc = self.lib.pam_upsample_add_nhwc_bf16(C.c_void_p(st), C.c_void_p(base.data_ptr()), len(terms), ptrs, sh,
-                                                 C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0)
+        cs = (C.c_int32 * 3)(*([t.stride(3) for t in terms] + [0] * (3 - len(terms))))       # terms may be channel slices
+        rc = self.lib.pam_upsample_add_nhwc_bf16_ex(C.c_void_p(st), C.c_void_p(base.data_ptr()), len(terms), ptrs, sh, cs,
+                                                    C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0)
         if rc != 0:
             raise _lib.PamError('pam_upsample_add_nhwc_bf16 failed (%d)' % rc)
         return y
@@ -157,6 +174,8 @@ class ConvEngine(object):
 
 class HipHRNet(ConvEngine):
     multi_stream = False
+    merge_fuse = True           # merged first-level fuse convolutions (False: one launch per convolution)
+    merge_up = True
 
     def __init__(self, folded_model, device):
         self.lib = _lib.load()
@@ -196,7 +215,31 @@ class HipHRNet(ConvEngine):
                 else:
                     r.append(('down', [P(step[0]) for step in f]))
             fuse.append(r)
-        return dict(branches=branches, fuse=fuse)
+        # the first strided conv of every down chain that starts from branch j reads the same tensor: ONE merged launch per source
+        # branch (final convs of 1-conv chains first = no ReLU, then the intermediates = ReLU), the chains continue from channel slices
+        merged = {}
+        for j in range(len(hm.branches)):
+            heads = [(i, hm.fuse_layers[i][j]) for i in range(len(hm.fuse_layers)) if i > j and hm.fuse_layers[i][j] is not None]
+            if len(heads) >= 2:
+                heads.sort(key=lambda t: (len(t[1]) > 1, t[0]))
+                op = PackedConv.merged([f[0][0] for _, f in heads], self.device)
+                parts, off = [], 0
+                for i, f in heads:
+                    parts.append((i, off, f[0][0].out_channels, len(f) == 1)); off += f[0][0].out_channels
+                relu_from = sum(c for _, _, c, final in parts if final)
+                if relu_from % 16 == 0:
+                    merged[j] = dict(op=op, parts=parts, relu_from=relu_from)
+        # likewise the 1x1 up-convolutions from branch j to every finer output i < j (all linear): one launch, the sums read slices
+        merged_up = {}
+        for j in range(len(hm.branches)):
+            ups = [(i, hm.fuse_layers[i][j]) for i in range(len(hm.fuse_layers)) if i < j and hm.fuse_layers[i][j] is not None]
+            if len(ups) >= 2:
+                op = PackedConv.merged([f[0] for _, f in ups], self.device)
+                parts, off = [], 0
+                for i, f in ups:
+                    parts.append((i, off, f[0].out_channels, j - i)); off += f[0].out_channels
+                merged_up[j] = dict(op=op, parts=parts)
+        return dict(branches=branches, fuse=fuse, merged=merged, merged_up=merged_up)
 
     # -- network ------------------------------------------------------------------------------------------------------
     # Stream plan (stream 0 = the caller's stream; hipGraph-capturable -- pairwise event dependencies between the branch streams
@@ -234,16 +277,27 @@ class HipHRNet(ConvEngine):
                     y = self.conv(c1, x, relu=True)
                     x = self.conv(c2, y, res=x, relu=True)
                 xs[b] = x
+                mg = mod['merged'].get(b) if self.merge_fuse else None
+                heads = {}
+                if mg is not None:                                    # first conv of all down chains from this branch in one launch
+                    y = self.conv(mg['op'], x, relu=True, relu_from=mg['relu_from'])
+                    heads = {i: y[:, off:off + c] for i, off, c, _ in mg['parts']}
+                mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up) else None
+                if mu is not None:                                    # all 1x1 up-convolutions from this branch in one launch
+                    y = self.conv(mu['op'], x)
+                    for i, off, c, sh in mu['parts']:
+                        terms[i][b] = (y[:, off:off + c], sh)
                 for i, row in enumerate(fuse):
                     f = row[b] if b < len(row) else None
-                    if f is None:
+                    if f is None or (f[0] == 'up' and mu is not None):
                         continue
                     if f[0] == 'up':
                         terms[i][b] = (self.conv(f[1], x), f[2])
                     else:
-                        t = x
-                        for k, op in enumerate(f[1]):
-                            t = self.conv(op, t, relu=(k < len(f[1]) - 1))
+                        t, ops = (heads[i], f[1][1:]) if i in heads else (x, f[1])
+                        k0 = len(f[1]) - len(ops)
+                        for k, op in enumerate(ops):
+                            t = self.conv(op, t, relu=(k0 + k < len(f[1]) - 1))
                         terms[i][b] = (t, 0)
         self._barrier()
         # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order

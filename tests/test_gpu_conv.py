@@ -97,3 +97,31 @@ def test_upsample_add_vs_torch():
                 ref = torch.relu(ref)
             torch.cuda.synchronize()
             assert torch.equal(y, ref.to(torch.bfloat16))
+
+
+def test_channel_sliced_operands_and_partial_relu():
+    """pam_conv2d_nhwc_bf16_ex / pam_upsample_add_nhwc_bf16_ex: input = channel slice of a wider tensor, ReLU only from a channel on,
+    sum terms = channel slices (the merged fuse-layer convolutions of HipHRNet)."""
+    from pam import _lib, hrnet_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(9)
+    e = hrnet_hip.ConvEngine(); e.lib = _lib.load(); e.device = dev
+    wide = torch.randn((2, 192, 24, 18), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    for (off, cin, cout, k, stride, relu_from) in [(96, 48, 192, 3, 2, 0), (144, 48, 48, 3, 2, 0), (0, 96, 144, 3, 2, 96), (48, 96, 96, 1, 1, 48)]:
+        conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=True)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * k * k)) ** 0.5); conv.bias.copy_(torch.randn(cout, generator=g))
+        op = hrnet_hip.PackedConv(conv, dev)
+        x = wide[:, off:off + cin]
+        y = e.conv(op, x, relu=True, relu_from=relu_from)
+        ref = F.conv2d(x.float(), conv.weight.detach().to(torch.bfloat16).float().to(dev), conv.bias.detach().to(dev), stride, k // 2)
+        ref = torch.cat([ref[:, :relu_from], torch.relu(ref[:, relu_from:])], 1)
+        torch.cuda.synchronize()
+        err = (y.float() - ref).abs()
+        assert bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all()), ((off, cin, cout, k, stride, relu_from), err.max().item())
+    base = torch.randn((2, 48, 24, 18), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    coarse = torch.randn((2, 96, 12, 9), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    out = e.upsample_add(base, [wide[:, 48:96], coarse[:, 48:96]], [0, 1], True)
+    ref = torch.relu(base.float() + wide[:, 48:96].float() + F.interpolate(coarse[:, 48:96].float(), scale_factor=2, mode='nearest'))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref.to(torch.bfloat16))

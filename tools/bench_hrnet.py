@@ -12,6 +12,7 @@ ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--modes', default='graph')
 ap.add_argument('--backends', default='hip,miopen')
 ap.add_argument('--no-branch-streams', action='store_true')
+ap.add_argument('--merge', type=int, default=2, help='0: no merged fuse convs, 1: strided chains only, 2: + up-convs')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 flops = hrnet.count_flops() * args.n
@@ -36,6 +37,7 @@ for backend in args.backends.split(','):
         net = hrnet.HRNetPose(48, 17, None, use_graph=(mode == 'graph'), backend=backend)
         if backend == 'hip':
             net.hip.multi_stream = not args.no_branch_streams
+            net.hip.merge_fuse = args.merge >= 1; net.hip.merge_up = args.merge >= 2
         x = net.input_buffer(args.n)
         x.copy_(torch.randn(x.shape, device=dev).to(x.dtype))
         net.heatmaps(x); torch.cuda.synchronize()
