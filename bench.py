@@ -156,7 +156,7 @@ def main():
         elapsed = float(tt.item())
     final = pipe.results()
 
-    # dominant kernel group: the HRNet conv stack (one hipGraph replay per frame = 308 launches of k_conv3x3 / k_conv_igemm /
+    # dominant kernel group: the HRNet conv stack (one hipGraph replay per frame = ~300 launches of k_conv3x3 / k_conv_igemm /
     # k_upsample_add), HIP events on the launch stream.  Arithmetic intensity 220 FLOP/B < the 312 FLOP/B ridge (2.5 PFLOP/s
     # over 8 TB/s): the stack is HBM-bound at this batch, so the roofline is quoted against HBM; the MFMA view is kept beside it.
     flops_crop = hrnet_mod.count_flops()
