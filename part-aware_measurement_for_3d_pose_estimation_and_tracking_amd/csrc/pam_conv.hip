@@ -581,7 +581,13 @@ static int launch_c3_one(hipStream_t s, const C3Args& a) {
     if (CIN / c3_ck(CIN) == 1 && !(a.dbg & 128)) {      // single-chunk layers: persistent workgroups (see the kernel)
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3<CIN, NTW, MT, NWAVES, PMAX>, 64 * NWAVES, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-        const int slots = 256 * per_cu / (int)grid.y / 8 * 8;
+        // One workgroup per CU while a workgroup has only a few tiles to walk: the layer then leaves half of every CU's LDS and
+        // registers to the kernels of the other branch streams (measured +2 % on the 20-crop forward; with two per CU the Cin-48
+        // chain shuts the other branches out and they run after it).  Large batches fill the chip on their own: all resident slots.
+        static const int cap = getenv("PAM_C3_PERSIST_SLOTS") ? atoi(getenv("PAM_C3_PERSIST_SLOTS")) : 0;     // tuning override
+        int slots = 256 * per_cu / (int)grid.y / 8 * 8;
+        const int few = cap > 0 ? cap : ((int)grid.x < 4 * 256 ? 256 : slots);
+        if (slots > few) slots = few / 8 * 8;
         if (slots >= 8 && (int)grid.x > slots) grid.x = slots;
     }
     hipLaunchKernelGGL((k_conv3x3<CIN, NTW, MT, NWAVES, PMAX>), grid, dim3(64 * NWAVES), lds, s, a);
