@@ -251,8 +251,12 @@ class HipHRNet(ConvEngine):
     #   * a join before every stage (the new branch's transition conv reads another stream's sum) and at the end.
     # Every tensor of a forward is kept alive until the forward has been issued (self._keep), so the caching allocator can never
     # hand a block that another stream still reads to a new tensor.
+    lane_of = (0, 1, 2, 3)      # stream of branch b (0 = the caller's stream); issue order of the branches inside a module
+    order = (0, 1, 2, 3)
+
     def _stream(self, b):
-        return None if (b == 0 or not self.multi_stream) else self.side[b - 1]
+        l = self.lane_of[b]
+        return None if (l == 0 or not self.multi_stream) else self.side[l - 1]
 
     def _barrier(self):
         """Join and re-fork all branch streams through the caller's stream."""
@@ -268,7 +272,8 @@ class HipHRNet(ConvEngine):
         xs = list(xs)
         fuse = mod['fuse']
         terms = [dict() for _ in fuse]
-        for b, blocks in enumerate(mod['branches']):
+        for b in [q for q in self.order if q < len(mod['branches'])]:
+            blocks = mod['branches'][b]
             with torch.cuda.stream(self._stream(b)):
                 x = xs[b]
                 if isinstance(x, tuple):                              # transition conv runs on the new branch's own stream
@@ -302,7 +307,7 @@ class HipHRNet(ConvEngine):
         self._barrier()
         # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order
         out = [None] * len(fuse)
-        for i in range(len(fuse)):
+        for i in [q for q in self.order if q < len(fuse)]:
             with torch.cuda.stream(self._stream(i)):
                 tl = [terms[i][j] for j in sorted(terms[i])]
                 out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])

@@ -12,6 +12,7 @@ ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--modes', default='graph')
 ap.add_argument('--backends', default='hip,miopen')
 ap.add_argument('--no-branch-streams', action='store_true')
+ap.add_argument('--lanes', default='0,1,2,3'); ap.add_argument('--order', default='0,1,2,3')
 ap.add_argument('--merge', type=int, default=2, help='0: no merged fuse convs, 1: strided chains only, 2: + up-convs')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
@@ -37,6 +38,7 @@ for backend in args.backends.split(','):
         net = hrnet.HRNetPose(48, 17, None, use_graph=(mode == 'graph'), backend=backend)
         if backend == 'hip':
             net.hip.multi_stream = not args.no_branch_streams
+            net.hip.lane_of = tuple(int(q) for q in args.lanes.split(',')); net.hip.order = tuple(int(q) for q in args.order.split(','))
             net.hip.merge_fuse = args.merge >= 1; net.hip.merge_up = args.merge >= 2
         x = net.input_buffer(args.n)
         x.copy_(torch.randn(x.shape, device=dev).to(x.dtype))
