@@ -192,6 +192,28 @@ int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, cons
 int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int n_terms, const void* const* terms, const int32_t* shifts,
                                   const int32_t* term_cstrides, void* out, int N, int H, int W, int C, int relu);
 
+/* ---- fused HRNet BasicBlock (row a1; stands inside the absent HRNet backend behind /root/reference/src/ivclabpose.py:210).
+ * out = ReLU(conv3x3(ReLU(conv3x3(in) + b1)) + b2 + in), NHWC bf16, C -> C -> C, stride 1, pad 1, BatchNorm folded; the
+ * intermediate never leaves LDS.  One launch runs the blocks of up to PAM_BLOCK_MAX_BRANCHES independent tensors (the
+ * branches of one HR module).  Supported C: 48, 96, 192 with W + 2 <= 76 / 40 / 24; pam_basic_block_rows returns the rows per
+ * work item for a workgroup shape (waves = 4 / 8, 0 = any; result 0 = not supported: use two pam_conv2d_nhwc_bf16 calls).
+ * w_img: 2 * NCH chunk images of CHB bytes (conv1's chunks, then conv2's); a chunk is KS consecutive k-step sub-images
+ * [C rows][PWT = 64 bytes = 4 pieces of 8 bf16]; k-step = 32 K elements, K = flattened (tap, cin) index padded with zeros to
+ * NSTEP*32; row R = output channel 48*(R/48) + 12*((R%16) >> 2) + 4*((R%48)/16) + (R & 3), and physical piece p of row R holds
+ * K elements 8*(p ^ s) .. +7 of the k-step with s = (0,2,3,1)[(R%16) >> 2] (LDS bank swizzle).
+ * pam_basic_block_chunk_layout writes {KS, NCH, PWT, CHB, NSTEP}.
+ * bias: float32 [2][C] (conv1, conv2).  in != out. */
+#define PAM_BLOCK_MAX_BRANCHES 4
+typedef struct PamBlockDesc {
+    const void* in; const void* w_img; const float* bias; void* out;
+    int32_t N, H, W, C;
+} PamBlockDesc;
+int pam_basic_block_rows(int C, int H, int W, int waves);
+int pam_basic_block_chunk_layout(int C, int32_t* out5);
+int pam_basic_block_nhwc_bf16(void* stream, int n_branches, const PamBlockDesc* blocks);
+/* waves: 4 = 256-thread workgroups, two per CU (C = 48 / 96 only), 8 = 512-thread workgroups, 0 = 4 when every branch allows it */
+int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* blocks, int waves);
+
 /* ---- person detector side (ivclabpose.py:116-120 constructs backend.YOLOv3, :183-204 PersonDetect calls it).
  * The backend is absent from the reference tree; these follow the public Darknet YOLOv3 definition (parity unpinned).
  * pam_resize_frames: n BGR uint8 frames (dev array of dev pointers, H x W x 3) -> bilinear (cv2.resize INTER_LINEAR

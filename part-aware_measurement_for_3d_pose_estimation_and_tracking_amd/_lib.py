@@ -28,6 +28,14 @@ class PamParams(C.Structure):
     ]
 
 
+class PamBlockDesc(C.Structure):
+    _fields_ = [('in_', C.c_void_p), ('w_img', C.c_void_p), ('bias', C.c_void_p), ('out', C.c_void_p),
+                ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32)]
+
+
+PAM_BLOCK_MAX_BRANCHES = 4
+
+
 class PamOutLayout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'n_views', 'max_dets', 'max_tracks', 'n_scenes', 'int_words', 'dbl_words', 'hdr_words', 'trk_words',
@@ -68,6 +76,10 @@ _SIGS = {
     'pam_conv_debug_stamps': (_I, [_P]),
     'pam_upsample_add_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
     'pam_upsample_add_nhwc_bf16_ex': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    'pam_basic_block_rows': (_I, [_I, _I, _I, _I]),
+    'pam_basic_block_chunk_layout': (_I, [_I, _P]),
+    'pam_basic_block_nhwc_bf16': (_I, [_P, _I, _P]),
+    'pam_basic_block_nhwc_bf16_ex': (_I, [_P, _I, _P, _I]),
     'pam_head_heatmaps': (_I, [_P, _I, _P, _I, _P, _P, _I, _P]),
     'pam_resize_frames': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'pam_upsample_concat_nhwc_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),

@@ -95,6 +95,38 @@ class PackedConv(object):
         return img
 
 
+class PackedBlock(object):
+    """One BasicBlock (conv3x3 -> ReLU -> conv3x3 -> + x -> ReLU) packed for ``pam_basic_block_nhwc_bf16``: the 2 * NCH weight
+    chunk images the kernel streams through LDS (layout: include/pam.h) and the [2][C] float32 bias."""
+
+    def __init__(self, conv1, conv2, device):
+        lib = _lib.load()
+        c = conv1.weight.shape[0]
+        assert conv1.weight.shape == (c, c, 3, 3) and conv2.weight.shape == (c, c, 3, 3)
+        lay = (C.c_int32 * 5)()
+        if lib.pam_basic_block_chunk_layout(c, lay) != 0:
+            raise _lib.PamError('no fused-block kernel for %d channels' % c)
+        ks, nch, pwt, chb, nstep = [int(v) for v in lay]
+        assert pwt == 64 and chb == ks * c * 64 and nstep == ks * nch and nstep * 32 >= 9 * c, (ks, nch, pwt, chb, nstep)
+        rows = torch.arange(c)
+        chan = 48 * (rows // 48) + 12 * ((rows % 16) >> 2) + 4 * ((rows % 48) // 16) + (rows & 3)
+        sigma = torch.tensor([0, 2, 3, 1])[(rows % 16) >> 2]                      # bank swizzle of the 16-byte pieces of a row
+        src = torch.arange(4)[None, :] ^ sigma[:, None]                            # physical piece p of row r holds logical piece p ^ sigma[r]
+        img = torch.zeros((2, nch, ks, c, 4, 8), dtype=torch.float32)
+        for cv, conv in enumerate((conv1, conv2)):
+            w = conv.weight.detach().float().permute(0, 2, 3, 1).reshape(c, 9 * c)[chan]       # [row][k = tap * C + cin]
+            wk = torch.zeros((c, nstep * 32), dtype=torch.float32)
+            wk[:, :9 * c] = w
+            wk = wk.reshape(c, nstep, 4, 8)                                        # [row][k-step][piece][8]
+            wk = torch.gather(wk, 2, src[:, None, :, None].expand(c, nstep, 4, 8))
+            img[cv] = wk.permute(1, 0, 2, 3).reshape(nch, ks, c, 4, 8)             # chunk = ks consecutive k-step sub-images [row][4][8]
+        self.w_img = img.to(torch.bfloat16).to(device).contiguous()
+        zb = lambda cv: cv.bias.detach().float() if cv.bias is not None else torch.zeros(c)
+        self.bias = torch.stack([zb(conv1), zb(conv2)]).to(device).contiguous()
+        self.c = c
+        self.c1 = self.c2 = None            # the unfused PackedConv pair (fallback for shapes the fused kernel does not take)
+
+
 class ConvEngine(object):
     """Kernel launchers shared by the pose network (HipHRNet) and the person detector (yolov3.HipDarknet)."""
     count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
@@ -130,6 +162,34 @@ class ConvEngine(object):
         if rc != 0:
             raise _lib.PamError('pam_conv2d_nhwc_bf16 failed (%d) for %s' % (rc, (x.shape, op.cout, op.kh, op.stride)))
         return y
+
+    def basic_blocks(self, ops, xs, waves=0):
+        """One launch: ops[i] (PackedBlock) applied to xs[i] (N, C, H, W channels-last bf16), for up to 4 independent tensors."""
+        assert 1 <= len(ops) == len(xs) <= _lib.PAM_BLOCK_MAX_BRANCHES
+        ys = []
+        descs = (_lib.PamBlockDesc * len(ops))()
+        for k, (op, x) in enumerate(zip(ops, xs)):
+            n, c, h, w = x.shape
+            assert c == op.c and (x.device.type == 'meta' or x.is_contiguous(memory_format=torch.channels_last)), (x.shape, op.c)
+            y = torch.empty_like(x)
+            ys.append(y)
+            if self._keep is not None:
+                self._keep.append(y)
+            if self.count is not None:       # unique bytes: input + both weight sets + biases + output (the residual is the input)
+                self.count['bytes'] += 2 * (x.numel() + y.numel() + 2 * 9 * c * c) + 8 * c
+                self.count['flops'] += 2 * 2 * y.numel() * 9 * c
+            if x.device.type != 'meta':
+                descs[k].in_ = x.data_ptr(); descs[k].w_img = op.w_img.data_ptr(); descs[k].bias = op.bias.data_ptr()
+                descs[k].out = y.data_ptr(); descs[k].N = n; descs[k].H = h; descs[k].W = w; descs[k].C = c
+        if self.count is not None:
+            self.count['launches'] += 1
+        if xs[0].device.type == 'meta':
+            return ys
+        st = torch.cuda.current_stream(xs[0].device).cuda_stream
+        rc = self.lib.pam_basic_block_nhwc_bf16_ex(C.c_void_p(st), len(ops), C.cast(descs, C.c_void_p), waves)
+        if rc != 0:
+            raise _lib.PamError('pam_basic_block_nhwc_bf16 failed (%d) for %s' % (rc, [tuple(x.shape) for x in xs]))
+        return ys
 
     def upsample_add(self, base, terms, shifts, relu):
         n, c, h, w = base.shape
@@ -204,6 +264,11 @@ class HipHRNet(ConvEngine):
     def _module(self, hm):
         P = lambda c: PackedConv(c, self.device)
         branches = [[(P(b.conv1), P(b.conv2)) for b in br] for br in hm.branches]
+        # the same blocks packed for the fused kernel (one launch per block, or per block LEVEL over several branches)
+        lib = _lib.load()
+        lay = (C.c_int32 * 5)()
+        fused = [[PackedBlock(b.conv1, b.conv2, self.device) for b in br] if lib.pam_basic_block_chunk_layout(br[0].conv1.out_channels, lay) == 0 else None
+                 for br in hm.branches]
         fuse = []
         for i, row in enumerate(hm.fuse_layers):
             r = []
@@ -239,7 +304,7 @@ class HipHRNet(ConvEngine):
                 for i, f in ups:
                     parts.append((i, off, f[0].out_channels, j - i)); off += f[0].out_channels
                 merged_up[j] = dict(op=op, parts=parts)
-        return dict(branches=branches, fuse=fuse, merged=merged, merged_up=merged_up)
+        return dict(branches=branches, fused=fused, fuse=fuse, merged=merged, merged_up=merged_up)
 
     # -- network ------------------------------------------------------------------------------------------------------
     # Stream plan (stream 0 = the caller's stream; hipGraph-capturable -- pairwise event dependencies between the branch streams
@@ -253,6 +318,9 @@ class HipHRNet(ConvEngine):
     # hand a block that another stream still reads to a new tensor.
     lane_of = (0, 1, 2, 3)      # stream of branch b (0 = the caller's stream); issue order of the branches inside a module
     order = (0, 1, 2, 3)
+    fuse_blocks = True          # BasicBlocks of the branches the fused kernel takes: one grouped launch per block level (caller's stream)
+    fuse_max_branches = 1       # ... at most this many leading branches (measured end to end at 20 crops: 1 -> 3.24 ms, 3 -> 3.46 ms, none -> 3.32 ms)
+    fuse_waves = 0              # workgroup shape of the fused kernel (0 = library default)
 
     def _stream(self, b):
         l = self.lane_of[b]
@@ -272,8 +340,37 @@ class HipHRNet(ConvEngine):
         xs = list(xs)
         fuse = mod['fuse']
         terms = [dict() for _ in fuse]
+        # which leading branches go through the fused, grouped kernel (shape supported by pam_basic_block_rows)
+        grouped = []
+        if self.fuse_blocks and xs[0] is not None:
+            for b in range(len(mod['branches'])):
+                shp = xs[b][2].shape if isinstance(xs[b], tuple) else xs[b].shape
+                cb = mod['branches'][b][0][0].cin
+                hb, wb = (shp[2], shp[3]) if not isinstance(xs[b], tuple) else ((shp[2] + 2 - 3) // xs[b][1].stride + 1, (shp[3] + 2 - 3) // xs[b][1].stride + 1)
+                if mod['fused'][b] is not None and len(grouped) == b and len(grouped) < min(self.fuse_max_branches, _lib.PAM_BLOCK_MAX_BRANCHES) and \
+                        self.lib.pam_basic_block_rows(cb, hb, wb, 0) > 0:
+                    grouped.append(b)
+        if grouped:
+            cur = torch.cuda.current_stream(self.device) if self.multi_stream else None
+            for b in grouped:                                         # transition convs of new branches: own stream, joined below
+                if isinstance(xs[b], tuple):
+                    with torch.cuda.stream(self._stream(b)):
+                        xs[b] = self.conv(xs[b][1], xs[b][2], relu=True)
+            if self.multi_stream:
+                for b in grouped:                                     # the branch streams hold the previous sums / transitions
+                    if self._stream(b) is not None:
+                        cur.wait_stream(self._stream(b))
+            ys = [xs[b] for b in grouped]
+            for k in range(len(mod['fused'][0])):
+                ys = self.basic_blocks([mod['fused'][b][k] for b in grouped], ys, self.fuse_waves)
+            for b, y in zip(grouped, ys):
+                xs[b] = y
+            if self.multi_stream:
+                for b in grouped:
+                    if self._stream(b) is not None:
+                        self._stream(b).wait_stream(cur)
         for b in [q for q in self.order if q < len(mod['branches'])]:
-            blocks = mod['branches'][b]
+            blocks = mod['branches'][b] if b not in grouped else []
             with torch.cuda.stream(self._stream(b)):
                 x = xs[b]
                 if isinstance(x, tuple):                              # transition conv runs on the new branch's own stream

@@ -1,0 +1,115 @@
+"""GPU: the fused BasicBlock kernel (csrc/pam_block.hip) against (a) a plain PyTorch fp32 reference of the same block on the same
+bf16-rounded inputs / weights (intermediate rounded to bf16 as the kernel stores it) and (b) the two-launch path through
+pam_conv2d_nhwc_bf16, over the HRNet-W48 branch shapes, ragged tiles, tiny images and grouped launches."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import pam
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, c, h, w
+    (2, 48, 96, 72),
+    (3, 96, 48, 36),
+    (3, 192, 24, 18),
+    (20, 48, 96, 72),        # full 20-crop shapes of the bench workload
+    (20, 96, 48, 36),
+    (20, 192, 24, 18),
+    (2, 48, 50, 72),         # ragged last tile (50 = 6 * 8 + 2)
+    (2, 96, 27, 36),
+    (2, 192, 13, 18),
+    (1, 48, 64, 48),         # 256x192 crops: 64 x 48 heat-maps
+    (2, 96, 32, 24),
+    (2, 192, 16, 12),
+    (3, 48, 7, 5),           # tiny images: one item, mostly junk tiles
+    (1, 192, 3, 4),
+]
+
+
+def make_block(c, seed):
+    g = torch.Generator().manual_seed(seed)
+    convs = []
+    for _ in range(2):
+        cv = nn.Conv2d(c, c, 3, 1, 1, bias=True)
+        with torch.no_grad():
+            cv.weight.copy_(torch.randn(cv.weight.shape, generator=g) * (2.0 / (9 * c)) ** 0.5)
+            cv.bias.copy_(torch.randn(c, generator=g) * 0.2)
+        convs.append(cv)
+    return convs
+
+
+def torch_block(x_bf16, c1, c2):
+    """fp32 reference on the bf16-rounded operands; the intermediate is rounded to bf16 like the kernel's LDS copy."""
+    x = x_bf16.float()
+    w1, w2 = c1.weight.to(torch.bfloat16).float().to(x.device), c2.weight.to(torch.bfloat16).float().to(x.device)
+    y = F.relu(F.conv2d(x, w1, c1.bias.to(x.device), 1, 1)).to(torch.bfloat16).float()
+    return F.relu(F.conv2d(y, w2, c2.bias.to(x.device), 1, 1) + x)
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from pam import _lib, hrnet_hip
+    e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
+    e.lib = _lib.load(); e.device = torch.device('cuda:0'); e.tile_cfg = -1
+    return e
+
+
+@pytest.mark.parametrize('waves', [4, 8])
+@pytest.mark.parametrize('case', CASES)
+def test_block_vs_torch_and_unfused(eng, case, waves):
+    from pam import hrnet_hip
+    n, c, h, w = case
+    dev = eng.device
+    if eng.lib.pam_basic_block_rows(c, h, w, waves) <= 0:
+        pytest.skip('shape not supported with %d waves' % waves)
+    c1, c2 = make_block(c, 100 + c + h)
+    g = torch.Generator().manual_seed(7 + n + h)
+    x = torch.randn((n, c, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    op = hrnet_hip.PackedBlock(c1, c2, dev)
+    y = eng.basic_blocks([op], [x], waves)[0]
+    torch.cuda.synchronize()
+    ref = torch_block(x, c1, c2)
+    err = (y.float() - ref).abs()
+    tol = 2e-2 + 1e-2 * ref.abs()                      # one bf16 rounding of the output + the intermediate's rounding boundary cases
+    assert bool((err <= tol).all()), (case, float(err.max()), float((err / tol).max()))
+    assert float(err.mean()) < 2e-3, float(err.mean())
+    # two-launch path: same MFMA products; the accumulation order over K may differ (chunking), so equal to within rounding
+    p1, p2 = hrnet_hip.PackedConv(c1, dev), hrnet_hip.PackedConv(c2, dev)
+    t = eng.conv(p1, x, relu=True)
+    u = eng.conv(p2, t, res=x, relu=True)
+    torch.cuda.synchronize()
+    d = (y.float() - u.float()).abs()
+    assert float(d.max()) <= 4e-2 + 1e-2 * float(u.float().abs().max()), float(d.max())
+    assert float((d > 0).float().mean()) < 0.05       # nearly every element is bit-equal
+    if c == 48:                                        # same K order as k_conv3x3<48>: bit-exact
+        assert torch.equal(y, u)
+
+
+def test_grouped_launch_equals_single(eng):
+    from pam import hrnet_hip
+    dev = eng.device
+    shapes = [(5, 48, 96, 72), (5, 96, 48, 36), (5, 192, 24, 18)]
+    ops, xs = [], []
+    for k, (n, c, h, w) in enumerate(shapes):
+        c1, c2 = make_block(c, 31 + k)
+        ops.append(hrnet_hip.PackedBlock(c1, c2, dev))
+        xs.append(torch.randn((n, c, h, w), generator=torch.Generator().manual_seed(k)).to(torch.bfloat16).to(dev)
+                  .contiguous(memory_format=torch.channels_last))
+    single = [eng.basic_blocks([o], [x], 8)[0] for o, x in zip(ops, xs)]
+    grouped = eng.basic_blocks(ops, xs)
+    rev = eng.basic_blocks(ops[::-1], xs[::-1])[::-1]
+    two4 = eng.basic_blocks(ops[:2], xs[:2], 4)                          # two workgroups per CU: same values (same K order per element)
+    torch.cuda.synchronize()
+    for a, b, c_ in zip(single, grouped, rev):
+        assert torch.equal(a, b) and torch.equal(a, c_)
+    assert torch.equal(two4[0], single[0]) and torch.equal(two4[1], single[1])
+
+
+def test_block_rejects_unsupported(eng):
+    assert eng.lib.pam_basic_block_rows(384, 12, 9, 0) == 0
+    assert eng.lib.pam_basic_block_rows(48, 96, 200, 0) == 0
+    assert eng.lib.pam_basic_block_rows(64, 96, 72, 0) == 0
+    assert eng.lib.pam_basic_block_rows(192, 24, 18, 4) == 0          # the 192-wide tile does not fit two workgroups per CU

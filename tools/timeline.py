@@ -6,7 +6,7 @@ import numpy as np
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end, stream_id, queue_id, grid_x/workgroup_x, grid_y from kernels order by start"))
 # the last replay = the last 315 conv/upsample kernels
-ks = [r for r in rows if r[0].startswith('void k_conv') or r[0].startswith('k_upsample')]
+ks = [r for r in rows if r[0].startswith('void k_conv') or r[0].startswith('k_upsample') or 'k_bblock' in r[0] or 'k_fuse' in r[0]]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 315
 ks = ks[-n:]
 t0 = ks[0][1]; t1 = max(k[2] for k in ks)
