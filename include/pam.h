@@ -153,6 +153,14 @@ int pam_op_hyp_cost(PamHandle* h, int n_members, const int32_t* cids, const doub
  * float32 FMA chain over the channels in order, starting from the bias. */
 int pam_head_heatmaps(void* stream, int n_pix, const void* feat_bf16, int C, const float* w, const float* bias, int J,
                       float* out);
+/* head + decode in one pass (what the product path runs): the same 1x1 convolution (bit-identical values) with the per-joint
+ * (max, first index) reduced on the fly -- the heat-maps are written only if dev_heatmaps_or_null is given.  feat: (n, hm_h, hm_w, C)
+ * bf16 NHWC; det / kp / view_of / slot_of / boxes as pam_decode_heatmaps; dev_scratch: pam_head_decode_scratch_bytes(n, hm_h, hm_w)
+ * bytes of device memory owned by the caller (per-tile candidates). */
+long long pam_head_decode_scratch_bytes(int n, int hm_h, int hm_w);
+int pam_head_decode(void* stream, int n, int hm_h, int hm_w, const void* feat_bf16, int C, const float* w, const float* bias, int J,
+                    float* dev_heatmaps_or_null, const int32_t* dev_view_of, const int32_t* dev_slot_of, const float* dev_boxes,
+                    int max_dets, double* dev_det, float* dev_kp_xyc, void* dev_scratch);
 int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames /*dev array of n_views frame ptrs*/,
                          int frame_h, int frame_w, const int32_t* dev_view_of, const float* dev_boxes,
                          int out_h, int out_w, int out_c /*3, or 8 = RGB + 5 zero channels*/, void* dev_out_bf16);
@@ -213,6 +221,22 @@ int pam_basic_block_chunk_layout(int C, int32_t* out5);
 int pam_basic_block_nhwc_bf16(void* stream, int n_branches, const PamBlockDesc* blocks);
 /* waves: 4 = 256-thread workgroups, two per CU (C = 48 / 96 only), 8 = 512-thread workgroups, 0 = 4 when every branch allows it */
 int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* blocks, int waves);
+
+/* ---- grouped launches for the HRNet fuse layers (row a1): several small independent convolutions / several fuse sums in ONE
+ * launch each -- a fuse layer is ~10 kernels of 10-40 us whose launch chain, not their arithmetic, is what takes time.
+ * pam_conv2d_group_nhwc_bf16: up to 8 convolutions with the arguments of pam_conv2d_nhwc_bf16_ex (Cout % 48 == 0, relu 0 / 1);
+ * pam_upsample_add_group_nhwc_bf16: up to 4 sums with the arguments of pam_upsample_add_nhwc_bf16_ex.  Outputs must not alias
+ * inputs of other members of the same group. */
+typedef struct PamConvDesc {
+    const void* in; const void* w_packed; const float* bias; const void* residual; void* out;
+    int32_t N, H, W, Cin, Cout, KH, KW, stride, pad, relu, in_cstride, relu_from;
+} PamConvDesc;
+int pam_conv2d_group_nhwc_bf16(void* stream, int n, const PamConvDesc* convs);
+typedef struct PamUpDesc {
+    const void* base; const void* terms[3]; void* out;
+    int32_t shifts[3]; int32_t term_cstrides[3]; int32_t n_terms, N, H, W, C, relu;
+} PamUpDesc;
+int pam_upsample_add_group_nhwc_bf16(void* stream, int n, const PamUpDesc* sums);
 
 /* ---- person detector side (ivclabpose.py:116-120 constructs backend.YOLOv3, :183-204 PersonDetect calls it).
  * The backend is absent from the reference tree; these follow the public Darknet YOLOv3 definition (parity unpinned).

@@ -36,6 +36,20 @@ class PamBlockDesc(C.Structure):
 PAM_BLOCK_MAX_BRANCHES = 4
 
 
+class PamConvDesc(C.Structure):
+    _fields_ = [('in_', C.c_void_p), ('w_packed', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p), ('out', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad', 'relu', 'in_cstride', 'relu_from')]
+
+
+class PamUpDesc(C.Structure):
+    _fields_ = [('base', C.c_void_p), ('terms', C.c_void_p * 3), ('out', C.c_void_p), ('shifts', C.c_int32 * 3),
+                ('term_cstrides', C.c_int32 * 3)] + [(n, C.c_int32) for n in ('n_terms', 'N', 'H', 'W', 'C', 'relu')]
+
+
+PAM_CONV_GROUP_MAX = 8
+PAM_UP_GROUP_MAX = 4
+
+
 class PamOutLayout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'n_views', 'max_dets', 'max_tracks', 'n_scenes', 'int_words', 'dbl_words', 'hdr_words', 'trk_words',
@@ -80,6 +94,10 @@ _SIGS = {
     'pam_basic_block_chunk_layout': (_I, [_I, _P]),
     'pam_basic_block_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_basic_block_nhwc_bf16_ex': (_I, [_P, _I, _P, _I]),
+    'pam_conv2d_group_nhwc_bf16': (_I, [_P, _I, _P]),
+    'pam_upsample_add_group_nhwc_bf16': (_I, [_P, _I, _P]),
+    'pam_head_decode_scratch_bytes': (C.c_longlong, [_I, _I, _I]),
+    'pam_head_decode': (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     'pam_head_heatmaps': (_I, [_P, _I, _P, _I, _P, _P, _I, _P]),
     'pam_resize_frames': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'pam_upsample_concat_nhwc_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),

@@ -90,7 +90,7 @@ __device__ __forceinline__ void c3_row_store(uint16_t* p, int g, const uint32_t*
 // (4 x NTW accumulator tiles of 16x16).  K is walked in chunks of 64; chunk c+1 is fetched (buffer_load, zero-fill by the
 // descriptor's range check, no branches) while chunk c is multiplied out of LDS.
 template <int NTW, int WM, int WN, bool GEN>
-__global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx, const int by) {
     constexpr int T = 64 * WM * WN, BM = 64 * WM, BN = 16 * NTW * WN;
     constexpr int APT = BM * 8 / T;                    // A pieces (16 B) per thread per chunk
     constexpr int BPT = (BN * 8 + T - 1) / T;          // B pieces per thread per chunk
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
     char* Bs = smem + 2 * BM * ROWB;                   // [2][BN][ROWB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const int kq = tid & 7;
     const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * a.in_cs * 2), 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Cout * a.Kpad * 2), 0x00020000);
@@ -252,6 +252,29 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
             c3_row_store<NTW>(a.out + o, g, ov);
         }
     }
+}
+
+template <int NTW, int WM, int WN, bool GEN>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
+    conv_igemm_body<NTW, WM, WN, GEN>(a, blockIdx.x, blockIdx.y);
+}
+
+// Several independent small convolutions in ONE launch (the convolutions of one level of an HRNet fuse layer: 1x1 up-convolutions
+// and strided 3x3 chains from every branch).  Workgroup b belongs to convolution g with first[g] <= b < first[g + 1]; inside it the
+// N tile varies fastest.  All use the 64-pixel x 48-channel single-wave tile: these layers are a few hundred such tiles each.
+#define PAM_CONV_GROUP_MAX 8
+struct ConvGroupArgs { ConvArgs c[PAM_CONV_GROUP_MAX]; int first[PAM_CONV_GROUP_MAX + 1]; int n; };
+__global__ __launch_bounds__(64) void k_conv_igemm_group(ConvGroupArgs g) {
+    const int b = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < PAM_CONV_GROUP_MAX; ++q) if (q < g.n && b >= g.first[q]) k = q;
+    ConvArgs a = g.c[0];
+    int f0 = g.first[0];
+#pragma unroll
+    for (int q = 1; q < PAM_CONV_GROUP_MAX; ++q) if (k == q) { a = g.c[q]; f0 = g.first[q]; }
+    const int nb = a.Cout / 48, l = b - f0;
+    conv_igemm_body<3, 1, 1, false>(a, l / nb, l - (l / nb) * nb);
 }
 
 template <int NTW, int WM, int WN>
@@ -849,5 +872,107 @@ extern "C" int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_upsample_add, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+extern "C" int pam_conv2d_group_nhwc_bf16(void* stream, int n, const PamConvDesc* d) {
+    if (n < 1 || n > PAM_CONV_GROUP_MAX || !d) return PAM_E_ARG;
+    ConvGroupArgs g;
+    g.n = n;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        const PamConvDesc& s = d[k];
+        const int in_cs = s.in_cstride > 0 ? s.in_cstride : s.Cin;
+        if (!s.in || !s.w_packed || !s.out || s.N <= 0 || s.H <= 0 || s.W <= 0 || s.Cin % 8 != 0 || s.Cout % 48 != 0 || s.KH < 1 || s.KW < 1 ||
+            s.KH > 3 || s.KW > 3 || s.stride < 1 || (s.relu != 0 && s.relu != 1) || in_cs < s.Cin || in_cs % 8 != 0 || s.relu_from < 0 ||
+            s.relu_from % 16 != 0 || s.H >= 32768 || s.W >= 32768)
+            return PAM_E_ARG;
+        ConvArgs& a = g.c[k];
+        a.in = (const uint16_t*)s.in; a.w = (const uint16_t*)s.w_packed; a.bias = s.bias; a.res = (const uint16_t*)s.residual; a.out = (uint16_t*)s.out;
+        a.N = s.N; a.H = s.H; a.W = s.W; a.Cin = s.Cin; a.Cout = s.Cout; a.KH = s.KH; a.KW = s.KW; a.stride = s.stride; a.pad = s.pad; a.relu = s.relu;
+        a.in_cs = in_cs; a.relu_from = s.relu_from;
+        a.Ho = (s.H + 2 * s.pad - s.KH) / s.stride + 1; a.Wo = (s.W + 2 * s.pad - s.KW) / s.stride + 1;
+        a.Ktot = s.KH * s.KW * s.Cin; a.Kpad = (a.Ktot + KC - 1) / KC * KC; a.M = s.N * a.Ho * a.Wo;
+        g.first[k] = blocks;
+        blocks += ((a.M + 63) / 64) * (s.Cout / 48);
+    }
+    for (int k = n; k < PAM_CONV_GROUP_MAX; ++k) { g.c[k] = g.c[0]; g.first[k] = blocks; }
+    g.first[PAM_CONV_GROUP_MAX] = blocks;
+    const size_t lds = 2 * (size_t)(64 + 48) * ROWB;
+    hipLaunchKernelGGL(k_conv_igemm_group, dim3(blocks), dim3(64), lds, (hipStream_t)stream, g);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+// the sums of ALL outputs of a fuse layer in one launch: workgroups [first[k], first[k + 1]) walk sum k
+#define PAM_UP_GROUP_MAX 4
+struct UpGroupArgs { UpArgs u[PAM_UP_GROUP_MAX]; int first[PAM_UP_GROUP_MAX + 1]; int n; };
+__device__ __forceinline__ void upsample_add_body(const UpArgs& a, unsigned b0, unsigned nblk) {
+    const unsigned C8 = (unsigned)a.C >> 3, total = (unsigned)a.N * a.H * a.W * C8;
+    for (unsigned e = b0 * 256 + threadIdx.x; e < total; e += nblk * 256) {
+        const unsigned pix = e / C8, c8 = e - pix * C8;
+        const unsigned t2 = pix / (unsigned)a.W, x = pix - t2 * a.W;
+        const unsigned n = t2 / (unsigned)a.H, y = t2 - n * a.H;
+        const bf16x8 b = *(const bf16x8*)(a.base + (size_t)pix * a.C + c8 * 8);
+        bf16x8 q[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            q[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < a.nterms) {
+                const unsigned hs = (unsigned)a.H >> a.sh[t], ws = (unsigned)a.W >> a.sh[t];
+                q[t] = *(const bf16x8*)(a.term[t] + ((size_t)(n * hs + (y >> a.sh[t])) * ws + (x >> a.sh[t])) * a.tcs[t] + c8 * 8);
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32((uint16_t)b[k]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < a.nterms) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32((uint16_t)q[t][k]);
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (short)f32_to_bf16_rne(a.relu ? fmaxf(v[k], 0.0f) : v[k]);
+        *(bf16x8*)(a.out + (size_t)pix * a.C + c8 * 8) = o;
+    }
+}
+__global__ __launch_bounds__(256) void k_upsample_add_group(UpGroupArgs g) {
+    const int b = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < PAM_UP_GROUP_MAX; ++q) if (q < g.n && b >= g.first[q]) k = q;
+    UpArgs a = g.u[0];
+    int f0 = g.first[0], f1 = g.first[1];
+#pragma unroll
+    for (int q = 1; q < PAM_UP_GROUP_MAX; ++q) if (k == q) { a = g.u[q]; f0 = g.first[q]; f1 = g.first[q + 1]; }
+    upsample_add_body(a, (unsigned)(b - f0), (unsigned)(f1 - f0));
+}
+
+extern "C" int pam_upsample_add_group_nhwc_bf16(void* stream, int n, const PamUpDesc* d) {
+    if (n < 1 || n > PAM_UP_GROUP_MAX || !d) return PAM_E_ARG;
+    UpGroupArgs g;
+    g.n = n;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        const PamUpDesc& s = d[k];
+        if (!s.base || !s.out || s.n_terms < 0 || s.n_terms > 3 || s.C % 8 != 0 || (size_t)s.N * s.H * s.W * (s.C / 8) >= (1ull << 31)) return PAM_E_ARG;
+        UpArgs& a = g.u[k];
+        a.base = (const uint16_t*)s.base; a.out = (uint16_t*)s.out; a.nterms = s.n_terms;
+        for (int t = 0; t < 3; ++t) {
+            a.term[t] = t < s.n_terms ? (const uint16_t*)s.terms[t] : nullptr; a.sh[t] = t < s.n_terms ? s.shifts[t] : 0;
+            a.tcs[t] = (t < s.n_terms && s.term_cstrides[t] > 0) ? s.term_cstrides[t] : s.C;
+            if (a.tcs[t] < s.C || a.tcs[t] % 8 != 0) return PAM_E_ARG;
+        }
+        a.N = s.N; a.H = s.H; a.W = s.W; a.C = s.C; a.relu = s.relu;
+        const size_t total = (size_t)s.N * s.H * s.W * (s.C / 8);
+        int nb = (int)((total + 255) / 256);
+        if (nb > 2048) nb = 2048;
+        g.first[k] = blocks;
+        blocks += nb;
+    }
+    for (int k = n; k < PAM_UP_GROUP_MAX; ++k) { g.u[k] = g.u[0]; g.first[k] = blocks; }
+    g.first[PAM_UP_GROUP_MAX] = blocks;
+    hipLaunchKernelGGL(k_upsample_add_group, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

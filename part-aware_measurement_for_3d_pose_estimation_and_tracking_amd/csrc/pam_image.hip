@@ -1,5 +1,6 @@
 // libpam_hip.so, image part of a1 (HRNetPose.predict pre/post-processing; call site /root/reference/src/ivclabpose.py:210).
-// The conv stack itself runs in PyTorch-ROCm; these two kernels bracket it.  Both are HBM-bound streaming kernels.
+// Crop / resize / normalise in front of the conv stack (csrc/pam_conv.hip, csrc/pam_block.hip), the network's final 1x1
+// convolution and the arg-max decode behind it.  All HBM-bound streaming kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/pam.h"
@@ -194,6 +195,96 @@ extern "C" int pam_head_heatmaps(void* stream, int n_pix, const void* feat_bf16,
     const size_t lds = ((size_t)J_ * C + (size_t)HEAD_T * J_) * sizeof(float);
     hipLaunchKernelGGL((k_head<PAM_J>), dim3((n_pix + HEAD_T - 1) / HEAD_T), dim3(HEAD_T), lds, (hipStream_t)stream, n_pix,
                        (const uint16_t*)feat_bf16, C, w, bias, out);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+// ---- head + arg-max in one pass: the heat-maps never reach memory ----------------------------------------------------------------
+// k_head_argmax: workgroup = 256 consecutive pixels of ONE crop; every thread has its pixel's J values in registers (same FMA
+// chain as k_head, so the values are bit-identical), the workgroup reduces (max, first index) per joint -- wave shuffles, then
+// the 4 waves through LDS -- and writes J candidates to cand[crop][tile][J].  k_argmax_finish: one wave per crop folds the
+// tiles in order (strictly greater replaces: the lowest flat index wins ties, np.argmax's rule) and writes the keypoint rows.
+template <int JN>
+__global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const uint16_t* __restrict__ feat, int C,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ heat /* optional */, Best* __restrict__ cand) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];       // [JN*C] weights, then Best[4][JN]
+    float* ws = hsm; Best* red = (Best*)(hsm + JN * C);
+    for (int i = threadIdx.x; i < JN * C; i += HEAD_T) ws[i] = w[i];
+    __syncthreads();
+    const int crop = blockIdx.x / tiles, tile = blockIdx.x - crop * tiles;
+    const int lp = tile * HEAD_T + threadIdx.x;                       // pixel inside the crop = flat heat-map index
+    const bool ok = lp < HW;
+    float acc[JN];
+#pragma unroll
+    for (int j = 0; j < JN; ++j) acc[j] = bias ? bias[j] : 0.0f;
+    if (ok) {
+        const uint16_t* f = feat + ((size_t)crop * HW + lp) * C;
+        for (int c8 = 0; c8 < C; c8 += 8) {
+            const uint4 v = *(const uint4*)(f + c8);
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { x[2 * k] = __uint_as_float(d[k] << 16); x[2 * k + 1] = __uint_as_float(d[k] & 0xffff0000u); }
+#pragma unroll
+            for (int j = 0; j < JN; ++j)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[j] = fmaf(x[k], ws[j * C + c8 + k], acc[j]);
+        }
+        if (heat) {
+            float* o = heat + ((size_t)crop * HW + lp) * JN;
+#pragma unroll
+            for (int j = 0; j < JN; ++j) o[j] = acc[j];
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+        Best b; b.v = ok ? acc[j] : -__builtin_huge_valf(); b.i = ok ? lp : 0x7fffffff;
+        b = wave_argmax(b);
+        if (lane == 0) red[wave * JN + j] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < JN) {
+        Best b = red[threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < HEAD_T / 64; ++q) b = better(b, red[q * JN + threadIdx.x]);
+        cand[((size_t)crop * tiles + tile) * JN + threadIdx.x] = b;
+    }
+}
+__global__ __launch_bounds__(64) void k_argmax_finish(int tiles, const Best* __restrict__ cand, int hm_h, int hm_w,
+                                                      const int* __restrict__ view_of, const int* __restrict__ slot_of,
+                                                      const float* __restrict__ boxes, int max_dets, double* __restrict__ det,
+                                                      float* __restrict__ kp) {
+    const int crop = blockIdx.x, j = threadIdx.x;
+    if (j >= J) return;
+    Best b; b.v = -__builtin_huge_valf(); b.i = 0x7fffffff;
+    for (int t = 0; t < tiles; ++t) {
+        const Best c = cand[((size_t)crop * tiles + t) * J + j];
+        if (c.v > b.v) b = c;                                         // tiles are in index order: strictly greater keeps the first maximum
+    }
+    double* row = det + ((size_t)view_of[crop] * max_dets + slot_of[crop]) * J * 3;
+    write_keypoint(j, b, hm_h, hm_w, boxes + crop * 4, row, kp ? kp + (size_t)crop * J * 3 : nullptr);
+}
+
+extern "C" long long pam_head_decode_scratch_bytes(int n, int hm_h, int hm_w) {
+    if (n < 0 || hm_h <= 0 || hm_w <= 0) return -1;
+    const long long tiles = ((long long)hm_h * hm_w + HEAD_T - 1) / HEAD_T;
+    return (long long)n * tiles * J * (long long)sizeof(Best);
+}
+
+extern "C" int pam_head_decode(void* stream, int n, int hm_h, int hm_w, const void* feat_bf16, int C, const float* w, const float* bias,
+                               int J_, float* dev_heatmaps_or_null, const int32_t* dev_view_of, const int32_t* dev_slot_of,
+                               const float* dev_boxes, int max_dets, double* dev_det, float* dev_kp_xyc, void* dev_scratch) {
+    if (n < 0 || !feat_bf16 || !w || !dev_view_of || !dev_slot_of || !dev_boxes || !dev_det || !dev_scratch || hm_h <= 0 || hm_w <= 0 ||
+        C <= 0 || C % 8 != 0 || J_ != PAM_J)
+        return PAM_E_ARG;
+    if (n == 0) return PAM_OK;
+    const int HW = hm_h * hm_w, tiles = (HW + HEAD_T - 1) / HEAD_T;
+    const size_t lds = (size_t)J_ * C * sizeof(float) + (size_t)(HEAD_T / 64) * J_ * sizeof(Best);
+    hipLaunchKernelGGL((k_head_argmax<PAM_J>), dim3(n * tiles), dim3(HEAD_T), lds, (hipStream_t)stream, HW, tiles,
+                       (const uint16_t*)feat_bf16, C, w, bias, dev_heatmaps_or_null, (Best*)dev_scratch);
+    hipLaunchKernelGGL(k_argmax_finish, dim3(n), dim3(64), 0, (hipStream_t)stream, tiles, (const Best*)dev_scratch, hm_h, hm_w,
+                       dev_view_of, dev_slot_of, dev_boxes, max_dets, dev_det, dev_kp_xyc);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 

@@ -273,10 +273,13 @@ class HRNetPose(object):
         self.stream = torch.cuda.current_stream(self.device)
 
     # -- conv stack (PyTorch-ROCm; hipGraph replay per batch size) -------------------------------------------------
-    def _forward(self, x):
+    def _forward(self, x, kind='heatmaps'):
         if self.backend != 'hip':
-            return self.head(self.model.features(x).float())
+            f = self.model.features(x)
+            return f if kind == 'features' else self.head(f.float())
         f = self.hip.features(x)                                        # (N, 48, h, w) channels-last bf16
+        if kind == 'features':
+            return f
         n, c, h, w = f.shape
         hm = torch.empty((n, self.head_w.shape[0], h, w), dtype=torch.float32, device=f.device, memory_format=torch.channels_last)
         rc = self.lib.pam_head_heatmaps(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), n * h * w,
@@ -288,28 +291,37 @@ class HRNetPose(object):
 
     def heatmaps(self, x):
         """x: (N,3,H,W) channels-last bf16 on the device -> (N,17,H/4,W/4) float32 (channels-last memory)."""
+        return self._run(x, 'heatmaps')
+
+    def features(self, x):
+        """x as above -> (N,48,H/4,W/4) channels-last bf16: the input of ``head_decode`` (the product path: the heat-maps are
+        never written)."""
+        return self._run(x, 'features')
+
+    def _run(self, x, kind):
         n = x.shape[0]
         if not self.use_graph:
             with torch.no_grad():
-                return self._forward(x)
-        g = self._graphs.get(n)
+                return self._forward(x, kind)
+        g = self._graphs.get((n, kind))
         if g is None:
-            static_in = torch.empty_like(x)
+            other = self._graphs.get((n, 'features' if kind == 'heatmaps' else 'heatmaps'))
+            static_in = other[1] if other is not None else torch.empty_like(x)     # one input buffer per batch size
             static_in.copy_(x)
             with torch.no_grad():
                 s = torch.cuda.Stream(self.device)
                 s.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(s):
                     for _ in range(2):
-                        self._forward(static_in)
+                        self._forward(static_in, kind)
                 torch.cuda.current_stream(self.device).wait_stream(s)
                 graph = torch.cuda.CUDAGraph()
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(graph, pool=self._pool):
-                    static_out = self._forward(static_in)
+                    static_out = self._forward(static_in, kind)
             g = (graph, static_in, static_out)
-            self._graphs[n] = g
+            self._graphs[(n, kind)] = g
         graph, static_in, static_out = g
         if static_in.data_ptr() != x.data_ptr():
             static_in.copy_(x)
@@ -319,7 +331,7 @@ class HRNetPose(object):
     def input_buffer(self, n):
         """The (N,3,H,W) channels-last bf16 tensor the preprocessing kernel writes; the graph's own input when one
         exists, so no copy is needed."""
-        g = self._graphs.get(n)
+        g = self._graphs.get((n, 'features')) or self._graphs.get((n, 'heatmaps'))
         if g is not None:
             return g[1]
         H, W = self.resolution
@@ -348,6 +360,26 @@ class HRNetPose(object):
                                           C.c_void_p(kp.data_ptr()) if kp is not None else None)
         if rc != 0:
             raise _lib.PamError('pam_decode_heatmaps failed: %d' % rc)
+
+    def head_decode(self, f, view_of, slot_of, boxes, det, kp=None, heat=None, n=None):
+        """Final 1x1 convolution + arg-max decode in one pass over the features f (N,48,h,w channels-last bf16): det rows as
+        ``decode``; the heat-maps are written only when ``heat`` (N,17,h,w float32 channels-last) is given.  n: decode only the
+        first n crops of f."""
+        nf, c, h, w = f.shape
+        n = nf if n is None else n
+        assert f.is_contiguous(memory_format=torch.channels_last) and f.dtype == torch.bfloat16 and n <= nf
+        need = int(self.lib.pam_head_decode_scratch_bytes(n, h, w))
+        if getattr(self, '_hd_scratch', None) is None or self._hd_scratch.numel() < need:
+            self._hd_scratch = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.pam_head_decode(C.c_void_p(st), n, h, w, C.c_void_p(f.data_ptr()), c, C.c_void_p(self.head_w.data_ptr()),
+                                      C.c_void_p(self.head_b.data_ptr()), self.head_w.shape[0],
+                                      C.c_void_p(heat.data_ptr()) if heat is not None else None,
+                                      C.c_void_p(view_of.data_ptr()), C.c_void_p(slot_of.data_ptr()), C.c_void_p(boxes.data_ptr()),
+                                      det.shape[1], C.c_void_p(det.data_ptr()), C.c_void_p(kp.data_ptr()) if kp is not None else None,
+                                      C.c_void_p(self._hd_scratch.data_ptr()))
+        if rc != 0:
+            raise _lib.PamError('pam_head_decode failed: %d' % rc)
 
     # -- the reference-shaped entry point ------------------------------------------------------------------------------
     def predict(self, person_bbox_list, batch_size=20, conf_threshold=0.4):
@@ -386,8 +418,10 @@ class HRNetPose(object):
                 vo = torch.cat([vo, vo[-1:].expand(mp - m)]); bb = torch.cat([bb, bb[-1:].expand(mp - m, 4)])
             x = self.input_buffer(mp)
             self.preprocess(ptrs, fh, fw, vo.contiguous(), bb.contiguous(), x)
-            hm = self.heatmaps(x)
-            self.decode(hm[:m], view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
+            if self.backend == 'hip':
+                self.head_decode(self.features(x), view_of[s:e].contiguous(), slot_of[s:e].contiguous(), bx[s:e].contiguous(), det, kp[s:e], n=m)
+            else:
+                self.decode(self.heatmaps(x)[:m], view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
         kp_h = kp.cpu().numpy()
         for i in range(n):
             k = kp_h[i].astype(np.float64)

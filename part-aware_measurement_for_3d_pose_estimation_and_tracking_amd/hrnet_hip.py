@@ -211,6 +211,72 @@ class ConvEngine(object):
             raise _lib.PamError('pam_upsample_add_nhwc_bf16 failed (%d)' % rc)
         return y
 
+    def conv_group(self, specs):
+        """One launch for several small independent convolutions.  specs: [(op, x, relu, relu_from)], x possibly a channel slice of a
+        wider channels-last tensor; returns the outputs in order."""
+        ys, descs = [], []
+        for op, x, relu, relu_from in specs:
+            n, cin, h, w = x.shape
+            in_cs = cin if x.device.type == 'meta' else x.stride(3)
+            assert cin == op.cin and op.cout % 48 == 0, (x.shape, op.cin, op.cout)
+            ho = (h + 2 * op.pad - op.kh) // op.stride + 1
+            wo = (w + 2 * op.pad - op.kw) // op.stride + 1
+            y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+            ys.append(y)
+            if self._keep is not None:
+                self._keep.append(y)
+            if self.count is not None:
+                self.count['bytes'] += 2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin) + 4 * op.cout
+                self.count['flops'] += 2 * y.numel() * op.kh * op.kw * op.cin
+            if x.device.type != 'meta':
+                d = _lib.PamConvDesc()
+                d.in_ = x.data_ptr(); d.w_packed = op.w.data_ptr(); d.bias = op.bias.data_ptr(); d.residual = None; d.out = y.data_ptr()
+                d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = n, h, w, op.cin, op.cout, op.kh, op.kw
+                d.stride, d.pad, d.relu, d.in_cstride, d.relu_from = op.stride, op.pad, 1 if relu else 0, in_cs, relu_from
+                descs.append(d)
+        if specs and specs[0][1].device.type != 'meta':
+            st = torch.cuda.current_stream(specs[0][1].device).cuda_stream
+        for i in range(0, len(specs), _lib.PAM_CONV_GROUP_MAX):
+            if self.count is not None:
+                self.count['launches'] += 1
+            if specs[0][1].device.type == 'meta':
+                continue
+            part = descs[i:i + _lib.PAM_CONV_GROUP_MAX]
+            arr = (_lib.PamConvDesc * len(part))(*part)
+            rc = self.lib.pam_conv2d_group_nhwc_bf16(C.c_void_p(st), len(part), C.cast(arr, C.c_void_p))
+            if rc != 0:
+                raise _lib.PamError('pam_conv2d_group_nhwc_bf16 failed (%d)' % rc)
+        return ys
+
+    def upsample_add_group(self, specs):
+        """One launch for all sums of a fuse layer.  specs: [(base, terms, shifts, relu)]."""
+        ys, descs = [], []
+        for base, terms, shifts, relu in specs:
+            n, c, h, w = base.shape
+            y = torch.empty_like(base)
+            ys.append(y)
+            if self._keep is not None:
+                self._keep.append(y)
+            if self.count is not None:
+                self.count['bytes'] += 2 * (2 * base.numel() + sum(t.numel() for t in terms))
+            if base.device.type != 'meta':
+                d = _lib.PamUpDesc()
+                d.base = base.data_ptr(); d.out = y.data_ptr(); d.n_terms = len(terms)
+                for k, t in enumerate(terms):
+                    d.terms[k] = t.data_ptr(); d.shifts[k] = shifts[k]; d.term_cstrides[k] = t.stride(3)
+                d.N, d.H, d.W, d.C, d.relu = n, h, w, c, 1 if relu else 0
+                descs.append(d)
+        if self.count is not None:
+            self.count['launches'] += 1
+        if specs[0][0].device.type == 'meta':
+            return ys
+        st = torch.cuda.current_stream(specs[0][0].device).cuda_stream
+        arr = (_lib.PamUpDesc * len(descs))(*descs)
+        rc = self.lib.pam_upsample_add_group_nhwc_bf16(C.c_void_p(st), len(descs), C.cast(arr, C.c_void_p))
+        if rc != 0:
+            raise _lib.PamError('pam_upsample_add_group_nhwc_bf16 failed (%d)' % rc)
+        return ys
+
     def upsample_concat(self, a, b):
         """Darknet upsample(x2) + route: concat(nearest_up2(a), b) along channels."""
         n, ca, h2, w2 = a.shape
@@ -320,7 +386,10 @@ class HipHRNet(ConvEngine):
     order = (0, 1, 2, 3)
     fuse_blocks = True          # BasicBlocks of the branches the fused kernel takes: one grouped launch per block level (caller's stream)
     fuse_max_branches = 1       # ... at most this many leading branches (measured end to end at 20 crops: 1 -> 3.24 ms, 3 -> 3.46 ms, none -> 3.32 ms)
-    fuse_waves = 0              # workgroup shape of the fused kernel (0 = library default)
+    fuse_waves = 8              # workgroup shape of the fused kernel (8 waves, one workgroup per CU, measured faster than 2 x 4 waves)
+    group_fuse = False          # True: fuse layers as one launch per LEVEL of convolutions over all branches + one launch for all sums
+                                # (99 launches per forward instead of 263, but the fuse convolutions no longer run beside the coarse
+                                # branches' chains: 3.50 ms vs 3.21 ms at 20 crops)
 
     def _stream(self, b):
         l = self.lane_of[b]
@@ -379,6 +448,8 @@ class HipHRNet(ConvEngine):
                     y = self.conv(c1, x, relu=True)
                     x = self.conv(c2, y, res=x, relu=True)
                 xs[b] = x
+                if self.group_fuse:
+                    continue
                 mg = mod['merged'].get(b) if self.merge_fuse else None
                 heads = {}
                 if mg is not None:                                    # first conv of all down chains from this branch in one launch
@@ -401,6 +472,8 @@ class HipHRNet(ConvEngine):
                         for k, op in enumerate(ops):
                             t = self.conv(op, t, relu=(k0 + k < len(f[1]) - 1))
                         terms[i][b] = (t, 0)
+        if self.group_fuse:
+            return self._fuse_grouped(mod, xs)
         self._barrier()
         # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order
         out = [None] * len(fuse)
@@ -408,6 +481,74 @@ class HipHRNet(ConvEngine):
             with torch.cuda.stream(self._stream(i)):
                 tl = [terms[i][j] for j in sorted(terms[i])]
                 out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])
+        return out
+
+    def _fuse_grouped(self, mod, xs):
+        """The fuse layer as grouped launches on the caller's stream: level 1 = every 1x1 up-convolution and the first strided
+        convolution of every down chain (per source branch these are already merged along Cout), level 2, 3 = the chains' next
+        convolutions, then ONE launch for the sums of all outputs.  Joins the branch streams before and re-forks them after."""
+        fuse = mod['fuse']
+        nb = len(mod['branches'])
+        if self.multi_stream:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.side:
+                cur.wait_stream(st)
+        terms = [dict() for _ in fuse]
+        pending = []                                                   # (target i, source b, remaining ops, index of the next op, chain length)
+        specs, sinks = [], []                                          # sinks[k](y): what to do with output k of this level
+        for b in range(nb):
+            x = xs[b]
+            mg = mod['merged'].get(b) if self.merge_fuse else None
+            heads_done = set()
+            if mg is not None:
+                def sink(y, mg=mg, b=b):
+                    for i, off, c, final in mg['parts']:
+                        t = y[:, off:off + c]
+                        f = fuse[i][b]
+                        if final:
+                            terms[i][b] = (t, 0)
+                        else:
+                            pending.append((i, b, t, f[1], 1))
+                specs.append((mg['op'], x, True, mg['relu_from'])); sinks.append(sink)
+                heads_done = {i for i, _, _, _ in mg['parts']}
+            mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up) else None
+            if mu is not None:
+                def sink_up(y, mu=mu, b=b):
+                    for i, off, c, sh in mu['parts']:
+                        terms[i][b] = (y[:, off:off + c], sh)
+                specs.append((mu['op'], x, False, 0)); sinks.append(sink_up)
+            for i, row in enumerate(fuse):
+                f = row[b] if b < len(row) else None
+                if f is None or (f[0] == 'up' and mu is not None) or (f[0] == 'down' and i in heads_done):
+                    continue
+                if f[0] == 'up':
+                    specs.append((f[1], x, False, 0)); sinks.append(lambda y, i=i, b=b, sh=f[2]: terms[i].__setitem__(b, (y, sh)))
+                else:
+                    ops = f[1]
+                    if len(ops) == 1:
+                        specs.append((ops[0], x, False, 0)); sinks.append(lambda y, i=i, b=b: terms[i].__setitem__(b, (y, 0)))
+                    else:
+                        specs.append((ops[0], x, True, 0)); sinks.append(lambda y, i=i, b=b, ops=ops: pending.append((i, b, y, ops, 1)))
+        while specs:
+            for y, sk in zip(self.conv_group(specs), sinks):
+                sk(y)
+            specs, sinks, nxt = [], [], pending
+            pending = []
+            for i, b, t, ops, k in nxt:
+                last = k == len(ops) - 1
+                specs.append((ops[k], t, not last, 0))
+                if last:
+                    sinks.append(lambda y, i=i, b=b: terms[i].__setitem__(b, (y, 0)))
+                else:
+                    sinks.append(lambda y, i=i, b=b, ops=ops, k=k: pending.append((i, b, y, ops, k + 1)))
+        sums = []
+        for i in range(len(fuse)):
+            tl = [terms[i][j] for j in sorted(terms[i])]
+            sums.append((xs[i], [t for t, _ in tl], [sh for _, sh in tl], True))
+        out = self.upsample_add_group(sums)
+        if self.multi_stream:
+            for st in self.side:
+                st.wait_stream(cur)
         return out
 
     def features(self, x8):

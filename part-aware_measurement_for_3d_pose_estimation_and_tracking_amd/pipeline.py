@@ -1,5 +1,5 @@
-"""On-device per-frame pipeline: crop/resize/normalise (HIP) -> HRNet-W48 conv stack (PyTorch-ROCm, hipGraph) ->
-heat-map decode (HIP) -> [all-gather of per-view keypoints when views are sharded] -> fused tracker frame kernel (HIP).
+"""On-device per-frame pipeline: crop/resize/normalise (HIP) -> HRNet-W48 conv stack (hand-written MFMA kernels, hipGraph replay) ->
+head + arg-max decode (HIP) -> [all-gather of per-view keypoints when views are sharded] -> fused tracker frame kernel (HIP).
 Nothing returns to the host inside a frame; the output record is copied out asynchronously.
 
 This is the device-resident form of testmodel.py's loop body (/root/reference/src/testmodel.py:59-69):
@@ -59,10 +59,10 @@ class FramePipeline(object):
         self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, view_local, boxes, x)
         if time_events is not None:
             time_events[0].record()
-        hm = self.net.heatmaps(x)
+        f = self.net.features(x)
         if time_events is not None:
             time_events[1].record()
-        self.net.decode(hm, view_local, slot_of, boxes, self.det_local)
+        self.net.head_decode(f, view_local, slot_of, boxes, self.det_local)
 
     def track_step(self, frame_id, n_det_local, det_local, fetch=True):
         """Exchange (if sharded) + fused tracker kernel on the gathered keypoints; async fetch of the record."""
@@ -73,6 +73,17 @@ class FramePipeline(object):
             self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
 
     # -- crop-balanced sharding ----------------------------------------------------------------------------------------------
+    def wait_track(self):
+        """Order the caller's stream behind the previous frame's exchange / tracker (they read ``crop_gather.send``): call before
+        ANY write to that buffer -- decode, or a caller that fills it itself."""
+        if self._track_pending:
+            torch.cuda.current_stream(self.device).wait_event(self.ev_track)
+
+    def write_send(self, rows):
+        """Copy keypoint rows (C, max_dets, 17, 3) into the exchange buffer, ordered behind the previous frame's readers."""
+        self.wait_track()
+        self.crop_gather.send.copy_(rows)
+
     def pose_step_crops(self, frame_ptrs, view_of, slot_of, boxes, time_events=None):
         """HRNet side for this rank's share of the frame's crops; view_of indexes ALL views (frame_ptrs has C entries).
         Decodes straight into the exchange buffer at (view, slot)."""
@@ -83,12 +94,11 @@ class FramePipeline(object):
         self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, view_of, boxes, x)
         if time_events is not None:
             time_events[0].record()
-        hm = self.net.heatmaps(x)
+        f = self.net.features(x)
         if time_events is not None:
             time_events[1].record()
-        if self._track_pending:                          # the previous frame's exchange still reads the buffer decode overwrites
-            torch.cuda.current_stream(self.device).wait_event(self.ev_track)
-        self.net.decode(hm, view_of, slot_of, boxes, self.crop_gather.send)
+        self.wait_track()
+        self.net.head_decode(f, view_of, slot_of, boxes, self.crop_gather.send)
 
     def track_step_crops(self, frame_id, n_det, select, fetch=True):
         """n_det (C,) int32 and select (CropGather.select_index) are the same on every rank (they follow from the frame's box

@@ -113,3 +113,38 @@ def test_block_rejects_unsupported(eng):
     assert eng.lib.pam_basic_block_rows(48, 96, 200, 0) == 0
     assert eng.lib.pam_basic_block_rows(64, 96, 72, 0) == 0
     assert eng.lib.pam_basic_block_rows(192, 24, 18, 4) == 0          # the 192-wide tile does not fit two workgroups per CU
+
+
+def test_grouped_fuse_launches_equal_single(eng):
+    """pam_conv2d_group_nhwc_bf16 / pam_upsample_add_group_nhwc_bf16 against one launch per member (same arithmetic, same K order)."""
+    from pam import hrnet_hip
+    dev = eng.device
+    g = torch.Generator().manual_seed(5)
+    mk = lambda n, c, h, w: torch.randn((n, c, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    x0, x1, x2 = mk(3, 48, 24, 18), mk(3, 96, 12, 9), mk(3, 192, 6, 5)
+    convs = [nn.Conv2d(48, 144, 3, 2, 1), nn.Conv2d(96, 48, 1, 1, 0), nn.Conv2d(192, 144, 1, 1, 0), nn.Conv2d(96, 192, 3, 2, 1)]
+    ops = [hrnet_hip.PackedConv(c, dev) for c in convs]
+    specs = [(ops[0], x0, True, 96), (ops[1], x1, False, 0), (ops[2], x2, False, 0), (ops[3], x1, True, 0)]
+    ys = eng.conv_group(specs)
+    torch.cuda.synchronize()
+    for (op, x, relu, rf), y in zip(specs, ys):
+        ref = eng.conv(op, x, relu=relu, relu_from=rf)
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref), (op.cin, op.cout)
+    # a channel slice as input (the chains continue from slices of a merged convolution's output)
+    sl = ys[0][:, 96:144]
+    op5 = hrnet_hip.PackedConv(nn.Conv2d(48, 192, 3, 2, 1), dev)
+    y5 = eng.conv_group([(op5, sl, False, 0)])[0]
+    ref5 = eng.conv(op5, sl)
+    torch.cuda.synchronize()
+    assert torch.equal(y5, ref5)
+    # sums
+    t1 = mk(3, 48, 12, 9); t2 = mk(3, 96, 6, 5)[:, :48]
+    b1 = mk(3, 96, 12, 9); u1 = mk(3, 96, 6, 5)
+    sums = [(x0, [t1, t2], [1, 2], True), (b1, [u1], [1], True), (x2, [], [], True)]
+    outs = eng.upsample_add_group(sums)
+    torch.cuda.synchronize()
+    for (base, terms, sh, relu), o in zip(sums, outs):
+        ref = eng.upsample_add(base, terms, sh, relu) if terms else torch.relu(base)
+        torch.cuda.synchronize()
+        assert torch.equal(o, ref)

@@ -191,10 +191,11 @@ def test_predict_dump_format_and_facade_end_to_end():
     for a, b in zip(dump, dump2):
         for ia, ib in zip(a, b):
             assert ia['keypoints'] == ib['keypoints']
-    assert model.pose_model.graph_bucket == 4 and 4 in model.pose_model._graphs and 3 not in model.pose_model._graphs   # 3 crops ran padded to 4
+    G = model.pose_model._graphs
+    assert model.pose_model.graph_bucket == 4 and (4, 'features') in G and (3, 'features') not in G   # 3 crops ran padded to 4
     model.pose_model.graph_bucket = 1                                                         # exact batch sizes: same result
     dump3 = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
-    assert 3 in model.pose_model._graphs
+    assert (3, 'features') in model.pose_model._graphs
     for a, b in zip(dump, dump3):
         for ia, ib in zip(a, b):
             assert ia['keypoints'] == ib['keypoints']
@@ -218,3 +219,50 @@ def test_head_kernel_vs_torch_fp32():
         ref = F.conv2d(f.float(), wt.reshape(17, 48, 1, 1), b)
         torch.cuda.synchronize()
         assert float((out - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-5
+
+
+def test_head_decode_fused_vs_two_kernels(net):
+    """pam_head_decode (1x1 head + arg-max in one pass, heat-maps optional) against pam_head_heatmaps + the torch arg-max reference:
+    identical heat-map values, identical keypoint rows, np.argmax's first-index rule on exact ties (engineered through the weights:
+    an all-zero head makes every map constant = its bias), ragged last tile, crops that are not the whole feature batch."""
+    import ctypes as C
+    from pam import hrnet, _lib
+    dev = net.device
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    for (n, h, w) in [(5, 96, 72), (3, 7, 5), (2, 33, 17)]:
+        f = torch.randn((n, 48, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+        # features with planted exact ties: two pixels of crop 1 get identical feature vectors that dominate joint 5
+        f[1 % n, :, 1, 2] = f[1 % n, :, 0, 1]
+        wt = (torch.randn((17, 48), generator=g) * 0.2).to(dev); b = torch.randn(17, generator=g).to(dev)
+        wt[3] = 0.0                                                    # joint 3: constant map -> index 0 must win
+        view_of = torch.arange(n, dtype=torch.int32, device=dev) % 3
+        slot_of = torch.arange(n, dtype=torch.int32, device=dev) // 3
+        boxes = (torch.rand((n, 4), generator=g) * 300 + 20).to(dev)
+        ref_hm = torch.empty((n, 17, h, w), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+        assert lib.pam_head_heatmaps(None, n * h * w, C.c_void_p(f.data_ptr()), 48, C.c_void_p(wt.data_ptr()), C.c_void_p(b.data_ptr()), 17,
+                                     C.c_void_p(ref_hm.data_ptr())) == 0
+        exp = hrnet.reference_decode(ref_hm, boxes)
+        old_w, old_b = net.head_w, net.head_b
+        net.head_w, net.head_b = wt.contiguous(), b.contiguous()
+        try:
+            for with_heat in (True, False):
+                det = torch.zeros((3, 4, 17, 3), dtype=torch.float64, device=dev)
+                kp = torch.zeros((n, 17, 3), dtype=torch.float32, device=dev)
+                heat = torch.full_like(ref_hm, 7.0) if with_heat else None
+                net.head_decode(f, view_of, slot_of, boxes, det, kp, heat=heat)
+                torch.cuda.synchronize()
+                if with_heat:
+                    assert torch.equal(heat, ref_hm)
+                for i in range(n):
+                    got = det[int(view_of[i]), int(slot_of[i])]
+                    assert torch.equal(got, exp[i]), (n, h, w, i, (got - exp[i]).abs().max())
+                    assert torch.equal(kp[i][:, 0].double(), exp[i][:, 1]) and torch.equal(kp[i][:, 1].double(), exp[i][:, 0])
+                assert float(det[0, 0, 3, 0]) == float(boxes[0, 1]) and float(det[0, 0, 3, 2]) == float(b[3])
+            # only the first m crops
+            det2 = torch.zeros((3, 4, 17, 3), dtype=torch.float64, device=dev)
+            net.head_decode(f, view_of[:1].contiguous(), slot_of[:1].contiguous(), boxes[:1].contiguous(), det2, n=1)
+            torch.cuda.synchronize()
+            assert torch.equal(det2[0, 0], exp[0]) and float(det2[1:].abs().max()) == 0.0
+        finally:
+            net.head_w, net.head_b = old_w, old_b
