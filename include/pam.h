@@ -65,7 +65,9 @@ typedef struct PamOutLayout {
     int32_t int_words;      /* int32 words per scene  */
     int32_t dbl_words;      /* float64 words per scene */
     /* int32 section: header then per-track blocks (list order = the reference's self.tracks order) */
-    int32_t hdr_words;      /* [0]=n_tracks [1]=status bits [2]=frame_id [3]=n_hyp (debug) */
+    int32_t hdr_words;      /* [0]=n_tracks [1]=status bits OF THIS FRAME: 1 = out of track slots, 2 = out of hypothesis slots,
+                             * 4 = an assignment problem was infeasible, 8 = a device-side detection count outside [0, max_dets]
+                             * was clamped (pam_frame_dev) [2]=frame_id [3]=n_hyp (debug) */
     int32_t trk_words;      /* words per track block */
     /* track block: 0 id,1 state,2 hits,3 age,4 time_since_update,5 emitted,6 n_2d_views,7 V (views offered to the
      * newest pose),8 history length,9 newest pose time, then order[n_views], matched_det[n_views] (index of the

@@ -17,6 +17,7 @@ using namespace pam;
 #define ST_TRACK_OVERFLOW 1
 #define ST_HYP_OVERFLOW 2
 #define ST_LSAP_INFEASIBLE 4
+#define ST_NDET_CLAMPED 8       /* a per-view detection count outside [0, max_dets] was clamped (pam_frame_dev takes device counts unchecked) */
 #define BLOCK 256
 
 struct Dims { int C, MAXP, MAXT, HCAP, MAXH, S, N1, N2; };
@@ -187,9 +188,17 @@ __global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
     double* out_d = A.out_d + (size_t)sidx * A.ol.dbl_words;
 #define DET(v, k) (det + ((size_t)(v) * MAXP + (k)) * J3)
     const int nT = st.hdr[0];
+    // device-side counts are not validated by the host (pam_frame_dev): clamp them so that no index leaves det / ws.taken
+#define NDET(v) min(max(n_det[v], 0), MAXP)
 
     // ---- P0: add_age, time gaps (IterativeTracker.py:126-129) -------------------------------------------------------
-    if (tid == 0) { out_d[0] = now_s(); ws.misc[1] = nT; }
+    if (tid == 0) {
+        out_d[0] = now_s(); ws.misc[1] = nT;
+        int bad = 0;
+        for (int v = 0; v < C; ++v) bad |= (n_det[v] < 0 || n_det[v] > MAXP);
+        st.hdr[2] = bad ? ST_NDET_CLAMPED : 0;                       // the status word is per frame (out_i[1]); nothing sticks
+    }
+    __syncthreads();
     for (int i = tid; i < nT; i += NT) {
         const int s = st.order[i];
         st.already[s] = 0; st.age[s] += 1; st.tsu[s] += 1;
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
     // ---- P1: re-projection affinity for every (view, track, detection) (:137-149) ----------------------------------
     for (int it = tid; it < C * nT * MAXP; it += NT) {
         const int v = it / (nT * MAXP), r = it % (nT * MAXP), i = r / MAXP, k = r % MAXP;
-        if (k >= n_det[v]) continue;
+        if (k >= NDET(v)) continue;
         const int s = st.order[i];
         const int newest = (st.h_head[s] + st.h_len[s] - 1) % HCAP;
         const int dt = ws.dt[i];
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
 
     // ---- P2: one assignment problem per view (:150-160) ---------------------------------------------------------
     for (int v = tid; v < C; v += NT) {
-        const int m = n_det[v];
+        const int m = NDET(v);
         if (nT > 0 && m > 0) {
             LsapScratch sc = lsap_carve(ws.lsap1 + (size_t)v * ((lsap_scratch_bytes(d.N1) + 7) & ~(size_t)7), d.N1);
             int* rows = ws.as_rows + v * d.N1; int* cols = ws.as_cols + v * d.N1;
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
     }
     for (int v = tid; v < C; v += NT) {
         int n = 0;
-        for (int k = 0; k < n_det[v]; ++k)
+        for (int k = 0; k < NDET(v); ++k)
             if (!ws.taken[v * MAXP + k] && believe(DET(v, k)) > prm.conf_threshold) ws.um_idx[v * MAXP + n++] = k;
         ws.um_n[v] = n;
     }

@@ -384,50 +384,88 @@ class HRNetPose(object):
     # -- the reference-shaped entry point ------------------------------------------------------------------------------
     def predict(self, person_bbox_list, batch_size=20, conf_threshold=0.4):
         """person_bbox_list[view] = list of dicts with 'bbox' [x, y, w, h] and 'data' (BGR uint8 HxWx3 ndarray or CUDA
-        tensor) -> dump_results[view] = list of dicts {bbox, keypoints (51: x, y, score), keypoints_score (17), feature}."""
-        views, boxes, frames = [], [], {}
+        tensor) -> dump_results[view] = list of dicts {bbox, keypoints (51: x, y, score), keypoints_score (17), feature}.
+
+        The returned list is a ``DumpResults``: besides the reference's dicts it keeps the decoded keypoints on the device in
+        the tracker's input layout ((views, max_dets, 17, 3) float64 rows (y, x, score) + per-view counts), so that
+        ``ivclabpose.PersonTrack_Project3DPose`` can hand them to the frame kernel without a host round trip when the caller
+        passes the dump on unchanged."""
+        V = len(person_bbox_list)
+        views, slots, boxes, frames, cnt = [], [], [], {}, [0] * V
         for v, persons in enumerate(person_bbox_list):
             for p in persons:
-                views.append(v); boxes.append(p['bbox'])
+                views.append(v); slots.append(cnt[v]); cnt[v] += 1; boxes.append(p['bbox'])
                 if v not in frames:
                     d = p['data']
                     if not torch.is_tensor(d):
                         d = torch.from_numpy(np.ascontiguousarray(d))
                     frames[v] = d.to(self.device, non_blocking=True).contiguous()
         n = len(views)
-        out = [[] for _ in person_bbox_list]
+        out = DumpResults([[] for _ in person_bbox_list])
         if n == 0:
             return out
         any_frame = next(iter(frames.values()))
         fh, fw = any_frame.shape[0], any_frame.shape[1]
-        ptrs = torch.tensor([frames[v].data_ptr() if v in frames else 0 for v in range(len(person_bbox_list))],
-                            dtype=torch.int64, device=self.device)
-        view_of = torch.tensor(views, dtype=torch.int32, device=self.device)
-        slot_of = torch.tensor([sum(1 for q in views[:i] if q == views[i]) for i in range(n)], dtype=torch.int32,
-                               device=self.device)
-        bx = torch.tensor(boxes, dtype=torch.float32, device=self.device).reshape(n, 4)
-        det = torch.zeros((len(person_bbox_list), max(self.max_dets, int(slot_of.max().item()) + 1), 17, 3),
-                          dtype=torch.float64, device=self.device)
+        # one upload for all the small per-call tables: [view_of n | slot_of n | boxes 4n (f32 bits) | n_det V | frame ptrs V (i64)]
+        meta = np.empty(6 * n + V + (V & 1) + 2 * V, dtype=np.int32)
+        meta[:n] = views; meta[n:2 * n] = slots
+        meta[2 * n:6 * n].view(np.float32)[:] = np.asarray(boxes, dtype=np.float32).reshape(-1)
+        meta[6 * n:6 * n + V] = cnt
+        o_ptr = 6 * n + V + (V & 1)
+        meta[o_ptr:].view(np.int64)[:] = [frames[v].data_ptr() if v in frames else 0 for v in range(V)]
+        m = torch.from_numpy(meta).to(self.device, non_blocking=True)
+        view_of, slot_of = m[:n], m[n:2 * n]
+        bx = m[2 * n:6 * n].view(torch.float32).reshape(n, 4)
+        n_det = m[6 * n:6 * n + V]
+        ptrs = m[o_ptr:].view(torch.int64)
+        det = torch.empty((V, max(self.max_dets, max(cnt)), 17, 3), dtype=torch.float64, device=self.device)
         kp = torch.empty((n, 17, 3), dtype=torch.float32, device=self.device)
         for s in range(0, n, batch_size):
             e = min(n, s + batch_size)
-            m = e - s
-            mp = min(batch_size, (m + self.graph_bucket - 1) // self.graph_bucket * self.graph_bucket) if batch_size >= self.graph_bucket else m
+            k = e - s
+            mp = min(batch_size, (k + self.graph_bucket - 1) // self.graph_bucket * self.graph_bucket) if batch_size >= self.graph_bucket else k
             vo, bb = view_of[s:e], bx[s:e]
-            if mp > m:                                   # pad with copies of the last crop
-                vo = torch.cat([vo, vo[-1:].expand(mp - m)]); bb = torch.cat([bb, bb[-1:].expand(mp - m, 4)])
+            if mp > k:                                   # pad with copies of the last crop
+                vo = torch.cat([vo, vo[-1:].expand(mp - k)]); bb = torch.cat([bb, bb[-1:].expand(mp - k, 4)])
             x = self.input_buffer(mp)
             self.preprocess(ptrs, fh, fw, vo.contiguous(), bb.contiguous(), x)
             if self.backend == 'hip':
-                self.head_decode(self.features(x), view_of[s:e].contiguous(), slot_of[s:e].contiguous(), bx[s:e].contiguous(), det, kp[s:e], n=m)
+                self.head_decode(self.features(x), view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e], n=k)
             else:
-                self.decode(self.heatmaps(x)[:m], view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
-        kp_h = kp.cpu().numpy()
+                self.decode(self.heatmaps(x)[:k], view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
+        kp_h = kp.cpu().numpy().astype(np.float64)       # the reference's contract is host lists: one device -> host copy per call
+        flat = kp_h.reshape(n, 51).tolist()
+        score = kp_h[:, :, 2].tolist()
         for i in range(n):
-            k = kp_h[i].astype(np.float64)
-            out[views[i]].append(dict(bbox=list(boxes[i]), keypoints=k.reshape(-1).tolist(),
-                                      keypoints_score=k[:, 2].tolist(), feature=[]))
+            out[views[i]].append(dict(bbox=list(boxes[i]), keypoints=flat[i], keypoints_score=score[i], feature=[]))
+        yxs = kp_h[:, :, [1, 0, 2]]
+        first = np.concatenate([[0], np.cumsum(cnt)])
+        out.attach(det, n_det, [yxs[first[v]:first[v + 1]] for v in range(V)])
         return out
+
+
+class DumpResults(list):
+    """``dump_results`` of the reference (list per view of person dicts) + the same keypoints still on the device."""
+    device_det = None        # (views, max_dets, 17, 3) float64 rows (y, x, score) at (view, slot)
+    device_n_det = None      # (views,) int32
+    poses_host = None        # per view (n, 17, 3) float64 (y, x, score): what ivclabpose._unpack would rebuild from the dicts
+
+    def attach(self, det, n_det, poses_host):
+        self.device_det, self.device_n_det, self.poses_host = det, n_det, poses_host
+        self._witness = [[(id(it), id(it['keypoints']), it['keypoints'][0], it['keypoints'][-1]) for it in items] for items in self]
+
+    def device_valid(self):
+        """True while the dicts are the ones predict() returned (same objects, same keypoint lists, end values untouched)."""
+        if self.device_det is None or len(self._witness) != len(self):
+            return False
+        for items, wit in zip(self, self._witness):
+            if len(items) != len(wit):
+                return False
+            for it, (a, b, k0, k1) in zip(items, wit):
+                k = it.get('keypoints')
+                if id(it) != a or id(k) != b or len(k) != 51 or k[0] != k0 or k[-1] != k1:
+                    return False
+        return True
 
 
 def smoke_check():

@@ -39,6 +39,7 @@ class FrameLoader(object):
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self.device = device
         self._pinned = {}
+        self._slot_events = {}
         self._lock = threading.Lock()
         if device is not None:
             import torch
@@ -74,14 +75,24 @@ class FrameLoader(object):
                 yield self.indices[k], imgs, ts
                 continue
             torch = self.torch
-            stage = self._slot_buffers(k % (self.depth + 1), [im.shape for im in imgs])
+            slot = k % (self.depth + 1)
+            stage = self._slot_buffers(slot, [im.shape for im in imgs])
+            prev = self._slot_events.get(slot)
+            if prev is not None:
+                prev.synchronize()                       # the earlier async copy out of this pinned slot has finished: safe to overwrite
             out = []
+            consumer = torch.cuda.current_stream(self.device)
             with torch.cuda.stream(self.copy_stream):
                 for im, pin in zip(imgs, stage):
                     pin.numpy()[...] = im
-                    out.append(pin.to(self.device, non_blocking=True))
+                    t = pin.to(self.device, non_blocking=True)
+                    # the block belongs to copy_stream's pool; the consumer reads it on ITS stream after only a wait_event, so tell
+                    # the caching allocator -- otherwise the block can be handed to the next frame's copy while kernels still read it
+                    t.record_stream(consumer)
+                    out.append(t)
                 ev = torch.cuda.Event(); ev.record(self.copy_stream)
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._slot_events[slot] = ev
+            consumer.wait_event(ev)
             yield self.indices[k], out, ts
 
     def close(self):

@@ -166,10 +166,17 @@ class ivclabpose(object):
         return out
 
     def PersonTrack_Project3DPose(self, frame_id, person_bbox_list=None, dump_results=None, build3D='SVD'):
-        poses = self._unpack(dump_results)
-        boxes = [np.array([it['bbox'] for it in items]) for items in dump_results]
-        frames = [(b[0]['data'] if len(b) else []) for b in person_bbox_list]
-        asso_time, update_time, init_time = self.tracker.tracking(frame_id, self.cameras, frames, boxes, poses, build3D)
+        dev = getattr(dump_results, 'device_det', None)
+        if dev is not None and dev.shape[1] == self.tracker.max_dets and dev.shape[0] == len(self.cameras) and dump_results.device_valid():
+            # the dump is the one PersonPoseDetect returned, untouched: its keypoints are still on the device in the tracker's
+            # layout -> no re-packing, no host -> device copy (the dicts stay the source of truth whenever the caller edits them)
+            poses = dump_results.poses_host
+            asso_time, update_time, init_time = self.tracker.tracking_dev(frame_id, self.cameras, dump_results.device_n_det, dev, build3D)
+        else:
+            poses = self._unpack(dump_results)
+            boxes = [np.array([it['bbox'] for it in items]) for items in dump_results]
+            frames = [(b[0]['data'] if len(b) else []) for b in person_bbox_list]
+            asso_time, update_time, init_time = self.tracker.tracking(frame_id, self.cameras, frames, boxes, poses, build3D)
         camera_ids, pts, person_ids, pts3d, pts3d_joints_views, person3d_ids = [], [], [], [], [], []
         for tr in self.tracker.tracks:
             if not tr.emitted:

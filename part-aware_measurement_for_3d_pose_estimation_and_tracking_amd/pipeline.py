@@ -121,8 +121,14 @@ class FramePipeline(object):
             self.ev_track.record(self.track_stream)
         self._track_pending = True
 
-    def results(self):
+    def results(self, strict=True):
+        """Synchronise and decode the last fetched record.  strict: a non-zero status word (capacity overflow, infeasible
+        assignment, clamped detection count -- include/pam.h) raises instead of passing silently into the caller's numbers."""
         if self.track_stream is not None:
             self.track_stream.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
-        return self.handle.decode(0, self.out_i.numpy(), self.out_d.numpy())
+        rec = self.handle.decode(0, self.out_i.numpy(), self.out_d.numpy())
+        if strict and rec['status'] != 0:
+            raise _lib.PamError('tracker status 0x%x on frame %d (1 track slots, 2 hypothesis slots, 4 infeasible assignment, 8 clamped '
+                                'detection count)' % (rec['status'], rec['frame_id']))
+        return rec

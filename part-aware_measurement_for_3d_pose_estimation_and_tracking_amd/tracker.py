@@ -93,7 +93,7 @@ class IterativeTracker(object):
 
     def tracking(self, frame_id, camera_list, frame_list, boxes_list, detections_list, build3D='SVD'):
         assert build3D == 'SVD', "Please modify BUILD3D to SVD when PERSON_MATCHER == Iterative"
-        if self.cameras is None or self.cameras is not camera_list and len(camera_list) != self.cam_num:
+        if self.cameras is None or self.cameras is not camera_list:     # the reference uses the camera_list of every call
             self.set_cameras(camera_list)
         self._ndet[:] = 0
         for v, dets in enumerate(detections_list):
@@ -106,5 +106,27 @@ class IterativeTracker(object):
         self.handle.frame(frame_id, self._ndet, self._det)
         self.last = self.handle.decode(0)
         self.tracks = [TrackView(r, self.cameras, detections_list) for r in self.last['tracks']]
+        c = self.last['clocks']
+        return float(c[1] - c[0]), float(c[2] - c[1]), float(c[3] - c[2])
+
+    def tracking_dev(self, frame_id, camera_list, dev_n_det, dev_det, build3D='SVD'):
+        """The same step on detections that are already on the device: dev_n_det (views,) int32, dev_det (views, max_dets, 17, 3)
+        float64 rows (y, x, score) CUDA tensors (what ``HRNetPose.predict`` keeps) -> no host packing, no host -> device copy;
+        one launch + one device -> host copy of the record."""
+        import torch
+        assert build3D == 'SVD', "Please modify BUILD3D to SVD when PERSON_MATCHER == Iterative"
+        if self.cameras is None or self.cameras is not camera_list:
+            self.set_cameras(camera_list)
+        if tuple(dev_det.shape) != (self.cam_num, self.max_dets, NUM_JOINTS, 3) or dev_det.dtype != torch.float64 or \
+                dev_n_det.dtype != torch.int32 or not dev_det.is_contiguous():
+            raise _lib.PamError('device detections %s do not match the tracker (%d views, max_dets=%d)' % (tuple(dev_det.shape), self.cam_num, self.max_dets))
+        st = torch.cuda.current_stream(dev_det.device).cuda_stream
+        self.handle.frame_dev(st, frame_id, dev_n_det.data_ptr(), dev_det.data_ptr())
+        self.handle.fetch(st)
+        self.handle.sync(st)
+        self.last = self.handle.decode(0)
+        if self.last['status'] != 0:
+            raise _lib.PamError('tracker status 0x%x (capacity overflow / infeasible assignment) on frame %d' % (self.last['status'], frame_id))
+        self.tracks = [TrackView(r, self.cameras, None) for r in self.last['tracks']]
         c = self.last['clocks']
         return float(c[1] - c[0]), float(c[2] - c[1]), float(c[3] - c[2])
