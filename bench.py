@@ -1,20 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: end-to-end multi-view frames/s of the per-frame hot path on synthetic Shelf-like frames
-(5 cameras, 1032x776, 4 persons -> 20 person crops per frame):
+"""Headline benchmark: end-to-end multi-view frames/s of the per-frame hot path on synthetic frames.
 
-    crop/resize/normalise (HIP) -> HRNet-W48 384x288 conv stack (hand-written MFMA HIP kernels, bf16, hipGraph) -> heat-map decode (HIP)
-    -> [one all-gather of per-view keypoints when views are sharded over ranks] -> fused tracker frame kernel (HIP):
-    association + part-aware epipolar view filter + weighted DLT + smoothing + hypothesis initialisation.
+    crop/resize/normalise (HIP) -> HRNet-W48 384x288 conv stack (hand-written MFMA HIP kernels, bf16, hipGraph replay)
+    -> head + arg-max decode (HIP) -> [ONE all-gather of per-view keypoints when the views are sharded over ranks]
+    -> fused tracker frame kernel (HIP): association + part-aware epipolar view filter + weighted DLT + smoothing + init.
 
-A step = one frame.  All inputs (frames, person boxes, synthetic 2D keypoints) are resident in HBM before the timed
-region.  As SURVEY 8d prescribes, HRNet runs on real shapes with seeded random weights (no checkpoints offline) and its
-decode output is computed but the tracker consumes the seeded synthetic keypoints, so association behaves realistically.
-One process per GPU (torch.distributed / RCCL); with --gpus N the camera views are partitioned over the N ranks.
+A step = one frame.  N = 1: the Shelf-like S2 workload (5 cameras 1032x776, 4 persons -> 20 crops per frame), the configuration
+BASELINE.json's metric is quoted on.  N > 1: the Panoptic-like S4 workload (31 cameras 1920x1080, 7 persons -> 217 crops per
+frame) with the CAMERA VIEWS partitioned over the ranks (each rank holds only its cameras' frames) and one all-gather of the
+per-view keypoint records per frame -- north_star's partition; the same line also carries the crop-balanced partition and rank 0
+running the whole S4 frame alone (the N = 1 point of the strong-scaling curve on the same workload).
 
-Prints ONE JSON line (rank 0).  See DESIGN.md 'Measurement' for how roofline / cpu_baseline are derived."""
+All inputs (frames, person boxes, synthetic 2D keypoints) are resident in HBM before the timed region.  As SURVEY 8d prescribes,
+HRNet runs on real shapes with seeded random weights (no checkpoints offline); its decode output is computed, and the tracker
+consumes the seeded synthetic keypoints so that association behaves realistically.
+
+`python bench.py --gpus N` starts its own N ranks (torch.distributed.run child, started before this process touches a GPU);
+under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.  Prints ONE JSON line (rank 0).
+See DESIGN.md 'Measurement' for how roofline / families / surface / cpu_baseline are derived."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0               # HBM3E spec, same table
+NAMES = {'S1': 'Campus', 'S2': 'Shelf', 'S3': 'Panoptic-5', 'S4': 'Panoptic-31'}
 
 
 def algorithmic_bytes_per_frame(C, P, T, V, L, J=17):
@@ -35,68 +43,60 @@ def algorithmic_bytes_per_frame(C, P, T, V, L, J=17):
     return det + T * per_track + out
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default='S2', choices=['S1', 'S2', 'S3', 'S4'])
+    ap.add_argument('--workload', default=None, choices=['S1', 'S2', 'S3', 'S4'], help='default: S2 on one GPU, S4 on several')
+    ap.add_argument('--shard', default=None, choices=['views', 'crops'], help='default: crops on one GPU (= no exchange), views on several')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-batched', action='store_true')
+    ap.add_argument('--no-families', action='store_true')
+    ap.add_argument('--no-surface', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='N > 1: skip the crop-balanced run and the single-GPU run of the same workload')
     ap.add_argument('--batched-scenes', type=int, default=2048)
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='run the tracker of frame t on the pose stream instead of under frame t+1')
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def launch_children(args):
+    """--gpus N without a launcher: start the N ranks ourselves, BEFORE this process initialises a GPU (device_count() does not),
+    relay rank 0's JSON line, exit non-zero if any rank failed.  Never re-executes a process that has touched the GPU."""
+    import socket
     import torch
-    import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    # test hooks (single-GPU boxes): PAM_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, PAM_BENCH_BACKEND=gloo swaps RCCL out
-    if os.environ.get('PAM_BENCH_SINGLE_DEVICE') == '1':
-        local_rank = 0
-    backend = os.environ.get('PAM_BENCH_BACKEND', 'nccl')
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda:%d' % local_rank))
-        else:
-            dist.init_process_group(backend)
-    assert args.gpus == world, '--gpus must equal the number of launched ranks (use torch.distributed.run for N>1)'
-    dev = torch.device('cuda:%d' % local_rank)
-    torch.cuda.set_device(dev)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:                   # single-GPU box: every rank on device 0, gloo instead of RCCL -- a functional check, not a scaling number
+        env['PAM_BENCH_SINGLE_DEVICE'] = '1'
+        env.setdefault('PAM_BENCH_BACKEND', 'gloo')
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    for l in lines[-1:]:
+        print(l, flush=True)
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(p.stdout[-4000:])
+        sys.exit(p.returncode or 1)
+    sys.exit(0)
 
-    import pam  # noqa: F401
-    from pam import synth, hrnet as hrnet_mod
-    from pam.ivclabpose import Camera, fundamental_matrices
-    from pam.pipeline import FramePipeline
 
-    size = args.workload
+def build_inputs(torch, synth, seq, size, max_dets, world, rank, shard, dev, nF):
+    """Frames, boxes and synthetic keypoints of THIS rank, resident in HBM.  views: the rank holds its own cameras' frames only and
+    view-local tables; crops: the frame's crops (ordered by view, then person) are dealt out evenly, every rank holds all frames."""
+    from pam.distributed import CropGather, view_partition
     meta = synth.SIZES[size]
-    C, P, fw, fh = meta['C'], meta['P'], meta['w'], meta['h']
-    K, W = args.steps, args.warmup
-    nF = K + W
-    seq = synth.make_sequence(size, n_frames=nF, seed=0)
-    dataset = synth.SIZE_TO_DATASET[size]
-    cfg = dict(synth.MATCHER_CFG[dataset]); conf = cfg.pop('CONF_THRESHOLD')
-    P32 = seq['calib']['P'].astype(np.float32); K32 = seq['calib']['K'].astype(np.float32)
-    RT32 = seq['calib']['RT'].astype(np.float32)
-    Fm = fundamental_matrices(K32, RT32)
-    cams = [Camera(j, P32[j], K32[j], RT32[j], Fm[j], w=fw, h=fh) for j in range(C)]
-    max_dets = 8
-    pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
-                         rank=rank, use_graph=not args.no_graph, shard='crops', overlap_tracker=not args.no_overlap)
-    from pam.distributed import CropGather
-
-    # ---- inputs resident in HBM.  The frame's crops (ordered by view, then person) are dealt out evenly over the ranks; every
-    # rank holds the (synthetic) frames of all views, its share of the boxes, and the synthetic keypoints of ITS crops only.
+    C, fw, fh = meta['C'], meta['w'], meta['h']
     g = torch.Generator().manual_seed(1234)
-    frames_dev = [torch.randint(0, 256, (fh, fw, 3), dtype=torch.uint8, generator=g).to(dev) for _ in range(C)]
-    frame_ptrs = torch.tensor([f.data_ptr() for f in frames_dev], dtype=torch.int64, device=dev)
+    all_frames = [torch.randint(0, 256, (fh, fw, 3), dtype=torch.uint8, generator=g) for _ in range(C)]   # same bytes on every rank
     n_det_all, det_all = synth.pack_frames(seq['frames'], max_dets)            # (F,C), (F,C,maxd,17,3) (y,x,s)
+    mine = view_partition(C, world)[rank] if shard == 'views' else list(range(C))
+    frames_dev = [all_frames[v].to(dev) for v in mine]
+    frame_ptrs = torch.tensor([f.data_ptr() for f in frames_dev] or [0], dtype=torch.int64, device=dev)
     per_frame, crops_per_frame, local_crops, parts_seen = [], [], [], None
     for t in range(nF):
         vl, sl, bx = [], [], []
@@ -105,43 +105,66 @@ def main():
                 x0, y0, x1, y1 = kp[:, 0].min(), kp[:, 1].min(), kp[:, 0].max(), kp[:, 1].max()
                 vl.append(v); sl.append(s)
                 bx.append([x0 - 0.125 * (x1 - x0), y0 - 0.125 * (y1 - y0), 1.25 * (x1 - x0), 1.25 * (y1 - y0)])
-        select, parts = CropGather.select_index(vl, sl, C, max_dets, world)
-        a, b = parts[rank]
-        mine_rows = np.full((C, max_dets, 17, 3), np.nan)                       # other ranks' rows must come through the exchange
-        for i in range(a, b):
-            mine_rows[vl[i], sl[i]] = det_all[t][vl[i], sl[i]]
-        if world == 1:
-            mine_rows = det_all[t]
-        per_frame.append((torch.tensor(vl[a:b], dtype=torch.int32, device=dev), torch.tensor(sl[a:b], dtype=torch.int32, device=dev),
-                          torch.tensor(bx[a:b], dtype=torch.float32, device=dev).reshape(-1, 4),
-                          torch.tensor(n_det_all[t], dtype=torch.int32, device=dev),
-                          torch.tensor(mine_rows, dtype=torch.float64, device=dev),
-                          torch.tensor(select, dtype=torch.int64, device=dev)))
-        crops_per_frame.append(len(vl)); local_crops.append(b - a)
+        if shard == 'views':
+            idx = [i for i in range(len(vl)) if vl[i] in mine]
+            loc = {v: k for k, v in enumerate(mine)}
+            ent = dict(vl=torch.tensor([loc[vl[i]] for i in idx], dtype=torch.int32, device=dev),
+                       sl=torch.tensor([sl[i] for i in idx], dtype=torch.int32, device=dev),
+                       bx=torch.tensor([bx[i] for i in idx], dtype=torch.float32, device=dev).reshape(-1, 4),
+                       nd=torch.tensor(n_det_all[t][mine] if mine else np.zeros(0), dtype=torch.int32, device=dev),
+                       dd=torch.tensor(det_all[t][mine] if mine else np.zeros((1, max_dets, 17, 3)), dtype=torch.float64, device=dev))
+            nloc = len(idx)
+            counts = [sum(1 for i in range(len(vl)) if vl[i] in p) for p in view_partition(C, world)]
+        else:
+            select, parts = CropGather.select_index(vl, sl, C, max_dets, world)
+            a, b = parts[rank]
+            rows = np.full((C, max_dets, 17, 3), np.nan)                        # other ranks' rows must come through the exchange
+            for i in range(a, b):
+                rows[vl[i], sl[i]] = det_all[t][vl[i], sl[i]]
+            if world == 1:
+                rows = det_all[t]
+            ent = dict(vl=torch.tensor(vl[a:b], dtype=torch.int32, device=dev), sl=torch.tensor(sl[a:b], dtype=torch.int32, device=dev),
+                       bx=torch.tensor(bx[a:b], dtype=torch.float32, device=dev).reshape(-1, 4),
+                       nd=torch.tensor(n_det_all[t], dtype=torch.int32, device=dev), dd=torch.tensor(rows, dtype=torch.float64, device=dev),
+                       sel=torch.tensor(select, dtype=torch.int64, device=dev))
+            nloc = b - a
+            counts = [q - p for p, q in parts]
+        per_frame.append(ent); crops_per_frame.append(len(vl)); local_crops.append(nloc)
         if len(vl) == int(np.median(crops_per_frame)):
-            parts_seen = [q - p for p, q in parts]
-    torch.cuda.synchronize()
+            parts_seen = counts
+    return dict(frames=frames_dev, ptrs=frame_ptrs, per_frame=per_frame, crops_per_frame=crops_per_frame, local_crops=local_crops,
+                parts=parts_seen, mine=mine, det_all=det_all, n_det_all=n_det_all)
 
-    def step(t, ev=None):
-        vl, sl, bx, nd, dd, sel = per_frame[t]
-        pipe.pose_step_crops(frame_ptrs, vl, sl, bx, ev)
-        pipe.crop_gather.send.copy_(dd)          # the tracker consumes the seeded synthetic keypoints, not the random net's
-        pipe.track_step_crops(t, nd, sel)
 
-    # ---- warm-up (includes hipGraph capture of every crop count that occurs) -------------------------------------------
-    for n in sorted(set(local_crops)):
+def make_step(pipe, inp, shard):
+    pf, ptrs = inp['per_frame'], inp['ptrs']
+    if shard == 'views':
+        def step(t, ev=None):
+            e = pf[t]
+            pipe.pose_step(ptrs, e['vl'], e['sl'], e['bx'], ev)
+            pipe.det_local.copy_(e['dd'])           # the tracker consumes the seeded synthetic keypoints, not the random net's
+            pipe.track_step(t, e['nd'], pipe.det_local)
+    else:
+        def step(t, ev=None):
+            e = pf[t]
+            pipe.pose_step_crops(ptrs, e['vl'], e['sl'], e['bx'], ev)
+            pipe.write_send(e['dd'])                # ordered behind the previous frame's exchange / tracker, which read that buffer
+            pipe.track_step_crops(t, e['nd'], e['sel'])
+    return step
+
+
+def timed_run(torch, dist, pipe, step, inp, K, W, world, dev, events=True):
+    """Warm-up (captures every crop count that occurs), then exactly K frames between barrier + synchronize pairs; MAX over ranks."""
+    for n in sorted(set(inp['local_crops'])):
         if n > 0 and pipe.net is not None:
-            x = pipe.net.input_buffer(n)
-            pipe.net.heatmaps(x)
+            pipe.net.features(pipe.net.input_buffer(n))
     for t in range(W):
         step(t)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-
-    # ---- timed region: exactly K frames -----------------------------------------------------------------------------
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)] if events else [None] * K
     t0 = time.perf_counter()
     for i in range(K):
         step(W + i, evs[i])
@@ -154,12 +177,68 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    final = pipe.results()
+    final = pipe.results()               # raises on a non-zero tracker status (capacity overflow etc.)
+    return elapsed, evs, final
 
-    # dominant kernel group: the HRNet conv stack (one hipGraph replay per frame = ~300 launches of k_conv3x3 / k_conv_igemm /
-    # k_upsample_add), HIP events on the launch stream.  Arithmetic intensity 220 FLOP/B < the 312 FLOP/B ridge (2.5 PFLOP/s
-    # over 8 TB/s): the stack is HBM-bound at this batch, so the roofline is quoted against HBM; the MFMA view is kept beside it.
-    flops_crop = hrnet_mod.count_flops()
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        launch_children(args)            # does not return
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # single-GPU boxes (set by launch_children when fewer devices than ranks exist): every rank on cuda:0, gloo instead of RCCL
+    single_dev = os.environ.get('PAM_BENCH_SINGLE_DEVICE') == '1'
+    if single_dev:
+        local_rank = 0
+    backend = os.environ.get('PAM_BENCH_BACKEND', 'nccl')
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda:%d' % local_rank))
+        else:
+            dist.init_process_group(backend)
+    assert args.gpus == world, '--gpus (%d) must equal the number of launched ranks (%d)' % (args.gpus, world)
+    dev = torch.device('cuda:%d' % local_rank)
+    torch.cuda.set_device(dev)
+
+    import pam  # noqa: F401
+    from pam import synth, hrnet as hrnet_mod
+    from pam.ivclabpose import Camera, fundamental_matrices
+    from pam.pipeline import FramePipeline
+    from pam.distributed import view_partition
+
+    size = args.workload or ('S2' if world == 1 else 'S4')
+    shard = args.shard or ('crops' if world == 1 else 'views')
+    meta = synth.SIZES[size]
+    C, P, fw, fh = meta['C'], meta['P'], meta['w'], meta['h']
+    K, W = args.steps, args.warmup
+    nF = K + W
+    seq = synth.make_sequence(size, n_frames=nF, seed=0)
+    dataset = synth.SIZE_TO_DATASET[size]
+    cfg = dict(synth.MATCHER_CFG[dataset]); conf = cfg.pop('CONF_THRESHOLD')
+    P32 = seq['calib']['P'].astype(np.float32); K32 = seq['calib']['K'].astype(np.float32)
+    RT32 = seq['calib']['RT'].astype(np.float32)
+    Fm = fundamental_matrices(K32, RT32)
+    cams = [Camera(j, P32[j], K32[j], RT32[j], Fm[j], w=fw, h=fh) for j in range(C)]
+    max_dets = 8
+    overlap = (not args.no_overlap) and shard == 'crops'
+    pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
+                         rank=rank, use_graph=not args.no_graph, shard=shard, overlap_tracker=overlap)
+    inp = build_inputs(torch, synth, seq, size, max_dets, world, rank, shard, dev, nF)
+    torch.cuda.synchronize()
+
+    # ---- the timed region: exactly K frames ------------------------------------------------------------------------------------
+    elapsed, evs, final = timed_run(torch, dist, pipe, make_step(pipe, inp, shard), inp, K, W, world, dev)
+
+    # dominant kernel group: the HRNet conv stack (one hipGraph replay per frame), HIP events on the launch stream
+    local_crops, crops_per_frame = inp['local_crops'], inp['crops_per_frame']
     work = {}
     for n in sorted(set(local_crops[W:])):
         if n > 0:
@@ -173,11 +252,9 @@ def main():
         achieved_gbs = float(np.sum(hr_by) / (np.sum(hr_ms) * 1e-3) / 1e9)
     else:
         avg_ms, achieved, achieved_gbs = 0.0, 0.0, 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_hrnet_hbm_traffic.json')
     n_med = int(np.median([n for n in local_crops[W:] if n > 0] or [0]))
-    if os.path.exists(tpath) and n_med == 20:
-        traffic = json.load(open(tpath))['hbm_bytes_per_forward']      # rocprofv3 PMC passes, tools/pmc_hrnet.sh (20 crops)
+    launches = work[n_med]['launches'] if n_med in work else 0
+    traffic, traffic_src = hbm_traffic(n_med, launches)
 
     out = None
     if rank == 0:
@@ -188,20 +265,49 @@ def main():
             'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'bf16 convs / f64 matching', 'data': 'synthetic',
             'config': {'workload': '%s-like %s: %d cams %dx%d, %d persons, %d crops/frame 384x288, 17 joints'
-                                   % ({'S1': 'Campus', 'S2': 'Shelf', 'S3': 'Panoptic-5', 'S4': 'Panoptic-31'}[size], size, C, fw, fh, P, int(np.median(crops_per_frame))),
-                       'crops_per_rank': parts_seen, 'sharding': 'crops dealt evenly over ranks', 'tracker': 'fused HIP frame kernel (f64)',
-                       'hrnet_weights': pipe.net.weights if pipe.net else None, 'conv_backend': pipe.net.backend if pipe.net else None, 'exchange': 'all_gather per frame' if world > 1 else 'none'},
-            'roofline': {'kernel': 'HRNet-W48 conv stack: k_conv3x3 / k_conv_igemm / k_upsample_add (hipGraph replay, %d crops, %d launches)'
-                                   % (n_med, work[n_med]['launches'] if n_med in work else 0),
+                                   % (NAMES[size], size, C, fw, fh, P, int(np.median(crops_per_frame))),
+                       'crops_per_rank': inp['parts'],
+                       'sharding': 'camera views partitioned over ranks, each rank holds its own cameras only' if shard == 'views'
+                                   else 'crops dealt evenly over ranks',
+                       'views_per_rank': [len(p) for p in view_partition(C, world)] if shard == 'views' else None,
+                       'tracker': 'fused HIP frame kernel (f64), replicated after the exchange', 'hrnet_weights': pipe.net.weights if pipe.net else None,
+                       'conv_backend': pipe.net.backend if pipe.net else None,
+                       'exchange': ('one all_gather_into_tensor per frame (%s)' % backend) if world > 1 else 'none',
+                       'devices': '%d ranks on ONE device (no multi-GPU box: functional check only)' % world if single_dev and world > 1 else '%d' % world},
+            'roofline': {'kernel': 'HRNet-W48 conv stack: k_bblock / k_conv3x3 / k_conv_igemm / k_upsample_add (hipGraph replay, %d crops, %d launches)'
+                                   % (n_med, launches),
                          'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'avg_launch_ms': avg_ms,
+                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': avg_ms,
                          'algorithmic_bytes': work[n_med]['bytes'] if n_med in work else None,
+                         'note': 'group-level view: 220 FLOP/B < the 312 FLOP/B ridge; the per-family bounds (hbm / mfma / latency) are in families[]',
                          'mfma': {'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'flops': work[n_med]['flops'] if n_med in work else None}},
-            'final_tracks': [t['track_id'] for t in final['tracks'] if t['emitted']],
+            'final_tracks': [t['track_id'] for t in final['tracks'] if t['emitted']], 'tracker_status': final['status'],
         }
 
-    # ---- secondary kernels (own HIP kernels), measured after the timed region -----------------------------------------
+    # ---- N > 1: the same frames with the crop-balanced partition, and rank 0 running the whole workload alone ---------------------------
+    if world > 1 and not args.no_extra:
+        other = 'crops' if shard == 'views' else 'views'
+        pipe2 = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world, rank=rank,
+                              use_graph=not args.no_graph, shard=other, overlap_tracker=(other == 'crops' and not args.no_overlap), net=pipe.net)
+        inp2 = build_inputs(torch, synth, seq, size, max_dets, world, rank, other, dev, nF)
+        el2, _, fin2 = timed_run(torch, dist, pipe2, make_step(pipe2, inp2, other), inp2, K, W, world, dev, events=False)
+        if rank == 0:
+            out['other_partition'] = {'sharding': other, 'value': K / el2, 'ms_per_step': el2 / K * 1e3, 'crops_per_rank': inp2['parts'],
+                                      'final_tracks': [t['track_id'] for t in fin2['tracks'] if t['emitted']]}
+        del pipe2, inp2
+        if rank == 0:
+            K1, W1 = min(K, 20), min(W, 3)
+            pipe1 = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=1, rank=0,
+                                  use_graph=not args.no_graph, shard='crops', overlap_tracker=not args.no_overlap, net=pipe.net)
+            inp1 = build_inputs(torch, synth, seq, size, max_dets, 1, 0, 'crops', dev, K1 + W1)
+            el1, _, fin1 = timed_run(torch, dist, pipe1, make_step(pipe1, inp1, 'crops'), inp1, K1, W1, 1, dev, events=False)
+            out['single_gpu_same_workload'] = {'value': K1 / el1, 'ms_per_step': el1 / K1 * 1e3, 'steps': K1,
+                                               'speedup_of_this_run': (K / elapsed) / (K1 / el1)}
+            del pipe1, inp1
+        dist.barrier()
+
+    # ---- secondary measurements on rank 0, after the timed region -------------------------------------------------------------------------
     if rank == 0:
         def ev_time(fn, iters=50):
             fn(); torch.cuda.synchronize()
@@ -211,23 +317,30 @@ def main():
                 fn()
             b.record(); torch.cuda.synchronize()
             return a.elapsed_time(b) / iters * 1e-3
-        tq = W + K - 1
-        vl, sl, bx, nd, dd, sel = per_frame[tq]
+        e = inp['per_frame'][W + K - 1]
+        vl, sl, bx = e['vl'], e['sl'], e['bx']
         n = int(vl.numel())
         kern = []
         if n > 0 and pipe.net is not None:
             x = pipe.net.input_buffer(n)
-            s = ev_time(lambda: pipe.net.preprocess(frame_ptrs, fh, fw, vl, bx, x))
+            s = ev_time(lambda: pipe.net.preprocess(inp['ptrs'], fh, fw, vl, bx, x))
             by = float((bx[:, 2] * bx[:, 3]).sum().item()) * 3 + n * x.shape[1] * 384 * 288 * 2
             kern.append({'kernel': 'k_preprocess_crops', 'bound': 'hbm', 'achieved': by / s / 1e9, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': by / s / 1e9 / HBM_PEAK_GBS, 'us': s * 1e6, 'bytes': by})
-            hm = pipe.net.heatmaps(x)
-            s = ev_time(lambda: pipe.net.decode(hm, vl, sl, bx, pipe.crop_gather.send))
-            by = n * (17 * 96 * 72 * 4 + 17 * 3 * 8)
-            kern.append({'kernel': 'k_decode_nhwc', 'bound': 'hbm', 'achieved': by / s / 1e9, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': by / s / 1e9 / HBM_PEAK_GBS, 'us': s * 1e6, 'bytes': by})
+            f = pipe.net.features(x)
+            det_tmp = torch.zeros((C, max_dets, 17, 3), dtype=torch.float64, device=dev)
+            s = ev_time(lambda: pipe.net.head_decode(f, vl, sl, bx, det_tmp))
+            by = n * (96 * 72 * 48 * 2 + 17 * 3 * 8)
+            kern.append({'kernel': 'k_head_argmax + k_argmax_finish (1x1 head + arg-max decode, heat-maps not written)', 'bound': 'hbm',
+                         'achieved': by / s / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': by / s / 1e9 / HBM_PEAK_GBS, 'us': s * 1e6, 'bytes': by})
         out['kernels'] = kern
-
+        if not args.no_families and n > 0 and pipe.net is not None and pipe.net.backend == 'hip':
+            fam = conv_families(torch, pipe.net, n, avg_ms)
+            out['roofline']['families'] = fam['families']
+            out['roofline']['families_note'] = fam['note']
+        if not args.no_surface and world == 1:
+            out['surface'] = surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, min(K, 60), min(W, 5))
+            out['surface']['frac_of_value'] = out['surface']['value'] / out['value']
         if not args.no_batched:
             out['tracker_batched'] = batched_tracker(torch, synth, cams, cfg, conf, size, args.batched_scenes, dev)
         if not args.no_cpu_baseline and world == 1:
@@ -237,6 +350,113 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def hbm_traffic(n_crops, launches):
+    """Counter-derived HBM bytes of one conv-stack forward: the newest profiles/r*_hrnet_hbm_traffic.json (tools/pmc_hrnet.sh: FETCH_SIZE and
+    WRITE_SIZE in separate rocprofv3 --pmc passes, FETCH doubled per the guide's gfx950 correction).  The figure is only reported when
+    the file was taken for the same crop count and the same number of launches per forward as the executor issues now; its commit travels
+    with it so a stale file cannot pose as a measurement of this build."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hrnet_hbm_traffic.json')))
+    if not files:
+        return None, None
+    path = files[-1]
+    j = json.load(open(path))
+    src = {'file': os.path.relpath(path, ROOT), 'commit': j.get('git_commit'), 'crops': j.get('crops', 20),
+           'launches_per_forward': j.get('launches_per_forward', j.get('FETCH_SIZE', {}).get('kernels_per_forward'))}
+    ok = src['crops'] == n_crops and src['launches_per_forward'] is not None and int(src['launches_per_forward']) == int(launches)
+    src['matches_this_build'] = bool(ok)
+    return (j['hbm_bytes_per_forward'] if ok else None), src
+
+
+def conv_families(torch, net, n, stack_ms):
+    """Per-kernel-family roofline of the conv stack: ONE eager forward on a single stream with HIP events around every launch (each
+    kernel alone on the chip), 3 repetitions averaged.  bound: 'mfma' / 'hbm' = the roof the family is closer to; 'latency' when it
+    reaches < 10 % of both (launch chain / occupancy bound: too few, too short workgroups)."""
+    hip = net.hip
+    x = net.input_buffer(n)
+    saved = (hip.multi_stream, hip.prof)
+    hip.multi_stream = False
+    reps = 3
+    runs = []
+    try:
+        with torch.no_grad():
+            hip.prof = None
+            hip.features(x); torch.cuda.synchronize()
+            for _ in range(reps):
+                hip.prof = []
+                hip.features(x)
+                torch.cuda.synchronize()
+                runs.append([(p['family'], p['bytes'], p['flops'], p['ev'][0].elapsed_time(p['ev'][1])) for p in hip.prof])
+    finally:
+        hip.multi_stream, hip.prof = saved
+    agg = {}
+    for run in runs:
+        for fam, by, fl, ms in run:
+            a = agg.setdefault(fam, dict(launches=0, bytes=0, flops=0, ms=0.0))
+            a['launches'] += 1; a['bytes'] += by; a['flops'] += fl; a['ms'] += ms
+    fams = []
+    for fam, a in agg.items():
+        L, by, fl, ms = a['launches'] / reps, a['bytes'] / reps, a['flops'] / reps, a['ms'] / reps
+        gbs, tfs = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
+        fh, fm = gbs / HBM_PEAK_GBS, tfs / MFMA_BF16_PEAK_TFLOPS
+        bound = 'latency' if max(fh, fm) < 0.10 else ('mfma' if fm >= fh else 'hbm')
+        fams.append({'kernel': fam, 'launches': int(round(L)), 'us_per_launch': ms * 1e3 / L, 'us_total': ms * 1e3,
+                     'algorithmic_bytes': int(by), 'flops': int(fl), 'bound': bound, 'frac': max(fh, fm),
+                     'hbm_frac': fh, 'mfma_frac': fm, 'achieved_GBs': gbs, 'achieved_TFLOPs': tfs})
+    fams.sort(key=lambda f: -f['us_total'])
+    serial = sum(f['us_total'] for f in fams) * 1e-3
+    return {'families': fams, 'note': 'each kernel alone on the chip (eager, one stream, HIP events per launch); sum %.3f ms vs %.3f ms for the '
+                                      'multi-stream hipGraph replay of the same forward' % (serial, stack_ms)}
+
+
+def surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, K, W):
+    """The drop-in surface exactly as /root/reference/src/testmodel.py:59-69 drives it: PersonPoseDetect(person_bbox_list) ->
+    PersonTrack_Project3DPose(frame_id, person_bbox_list, dump_results, 'SVD'), frames resident in HBM ('data' = CUDA tensors),
+    9-tuple returned to the host every frame.  The dump goes from one call to the next unchanged, so the tracker takes the
+    keypoints from the device buffer predict() kept; as in the main loop the synthetic keypoints are substituted (on the device)."""
+    import contextlib
+    import io
+    from pam.ivclabpose import ivclabpose
+    mcfg = dict(cfg)
+    with contextlib.redirect_stdout(io.StringIO()):      # the reference's constructor prints its configuration; stdout carries the JSON line only
+        model = ivclabpose({'NAME': ''}, None, dict(mcfg, NAME='Iterative'), conf, max_dets=max_dets, max_tracks=16, device=pipe.device.index)
+    model.pose_model = pipe.net                       # same network object (weights, packed images, graphs)
+    model.pose_model.max_dets = max_dets
+    model.cameras = cams
+    model.tracker.set_cameras(cams)
+    C = len(cams)
+    frames = inp['frames'] if len(inp['frames']) == C else None
+    assert frames is not None
+    pbls = []
+    for t in range(K + W):
+        e = inp['per_frame'][t]
+        vl, bx = e['vl'].tolist(), e['bx'].tolist()
+        pbl = [[] for _ in range(C)]
+        for v, b in zip(vl, bx):
+            pbl[v].append(dict(image_id=t, category_id=1, score=0.9, bbox=b, data=frames[v], feature=[]))
+        pbls.append(pbl)
+    det_dev = [torch.tensor(inp['det_all'][t], dtype=torch.float64, device=pipe.device) for t in range(K + W)]
+    det_host = [[inp['det_all'][t][v][:inp['n_det_all'][t][v]] for v in range(C)] for t in range(K + W)]
+    emitted = 0
+
+    def one(t):
+        dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbls[t], batch_size=max(20, len(sum(pbls[t], []))))
+        dump.device_det.copy_(det_dev[t]); dump.poses_host = det_host[t]      # synthetic keypoints instead of the random net's (SURVEY 8d)
+        return model.PersonTrack_Project3DPose(t, pbls[t], dump, 'SVD')
+    for t in range(W):
+        one(t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        r = one(t)
+        emitted += len(r[5])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {'value': K / el, 'unit': 'frames/s', 'ms_per_step': el / K * 1e3, 'steps': K, 'emitted_poses': emitted,
+            'what': 'ivclabpose.PersonPoseDetect + PersonTrack_Project3DPose per frame (host lists out of predict, 9-tuple out of the tracker; '
+                    'keypoints handed over on the device)'}
 
 
 def batched_tracker(torch, synth, cams, cfg, conf, size, B, dev, n_frames=40, distinct=8):
@@ -278,9 +498,10 @@ def batched_tracker(torch, synth, cams, cfg, conf, size, B, dev, n_frames=40, di
 def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
     """The CPU path timed on this box's host cores, bounded sample: (i) the oracle (NumPy restatement of the reference's
     matching path, single thread like the reference) over the first frames; (ii) the same HRNet-W48 module in fp32 on CPU
-    PyTorch with all cores, a few crops, scaled to the workload's crops/frame.  end-to-end fps = 1/(t_hrnet + t_match)."""
+    PyTorch, a few crops, EXTRAPOLATED linearly to the workload's crops/frame.  end-to-end fps = 1/(t_hrnet + t_match)."""
     from oracle import cpu_ref as O
-    ncores = os.cpu_count()
+    ncpu = os.cpu_count()
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else ncpu
     ref = O.OracleIvclabpose(cfg, conf)
     ref.GetCameraParameters(seq['calib'], F=Fm)
     n_match = min(len(seq['frames']), 100)
@@ -292,7 +513,6 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
     model = hrnet_mod.fold_batchnorm(hrnet_mod.init_random(hrnet_mod.PoseHighResolutionNet())).eval()
     n_crops = 2
     x = torch.randn(n_crops, 3, 384, 288)
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else ncores
     best_thr, best_t = 1, None
     with torch.no_grad():
         # os.cpu_count() can exceed what the container may really use (cgroup quota): pick the thread count that is
@@ -315,12 +535,13 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
         while reps < 1 or (time.perf_counter() - t0 < 8.0 and reps < 8):
             model(x); reps += 1
         t_crop = (time.perf_counter() - t0) / (reps * n_crops)
-    ncores = best_thr
     crops = float(np.median(crops_per_frame))
     t_hr = t_crop * crops
-    return {'value': 1.0 / (t_hr + t_match), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
-            'sample': 'oracle tracker (1 thread) over %d frames: %.2f ms/frame; HRNet-W48 fp32 CPU PyTorch (%d threads, fastest of the probed counts) %d reps x %d crops: '
-                      '%.3f s/crop x %d crops/frame' % (n_match, t_match * 1e3, ncores, reps, n_crops, t_crop, int(crops)),
+    return {'value': 1.0 / (t_hr + t_match), 'unit': 'frames/s', 'cores': avail, 'cpu_count': ncpu, 'affinity_cores': avail,
+            'threads': best_thr, 'kind': 'port (HRNet time extrapolated from %d crops to %d)' % (n_crops, int(crops)),
+            'sample': 'oracle tracker (1 thread) over %d frames: %.2f ms/frame; HRNet-W48 fp32 CPU PyTorch (%d threads = fastest of the probed counts, '
+                      '%d cores usable of %d) %d reps x %d crops: %.3f s/crop x %d crops/frame'
+                      % (n_match, t_match * 1e3, best_thr, avail, ncpu, reps, n_crops, t_crop, int(crops)),
             'match_ms_per_frame': t_match * 1e3, 'hrnet_s_per_frame': t_hr}
 
 

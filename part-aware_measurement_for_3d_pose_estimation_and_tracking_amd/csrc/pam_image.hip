@@ -201,7 +201,7 @@ extern "C" int pam_head_heatmaps(void* stream, int n_pix, const void* feat_bf16,
 // ---- head + arg-max in one pass: the heat-maps never reach memory ----------------------------------------------------------------
 // k_head_argmax: workgroup = 256 consecutive pixels of ONE crop; every thread has its pixel's J values in registers (same FMA
 // chain as k_head, so the values are bit-identical), the workgroup reduces (max, first index) per joint -- wave shuffles, then
-// the 4 waves through LDS -- and writes J candidates to cand[crop][tile][J].  k_argmax_finish: one wave per crop folds the
+// LDS staging, 8 lanes per joint -- and writes J candidates to cand[crop][tile][J].  k_argmax_finish: one wave per crop folds the
 // tiles in order (strictly greater replaces: the lowest flat index wins ties, np.argmax's rule) and writes the keypoint rows.
 template <int JN>
 __global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const uint16_t* __restrict__ feat, int C,
@@ -236,19 +236,27 @@ __global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const
             for (int j = 0; j < JN; ++j) o[j] = acc[j];
         }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // per-joint (max, first index) over the workgroup's 256 pixels: the values go through LDS pixel-major (pitch JN + 1 words: the
+    // column reads below are conflict-free), then 8 lanes per joint scan 32 pixels each in index order and fold by 3 shuffles
+    float* vs = (float*)(red + (HEAD_T / 64) * JN);                   // [HEAD_T][JN + 1]
 #pragma unroll
-    for (int j = 0; j < JN; ++j) {
-        Best b; b.v = ok ? acc[j] : -__builtin_huge_valf(); b.i = ok ? lp : 0x7fffffff;
-        b = wave_argmax(b);
-        if (lane == 0) red[wave * JN + j] = b;
-    }
+    for (int j = 0; j < JN; ++j) vs[threadIdx.x * (JN + 1) + j] = ok ? acc[j] : -__builtin_huge_valf();
     __syncthreads();
-    if (threadIdx.x < JN) {
-        Best b = red[threadIdx.x];
+    if (threadIdx.x < JN * 8) {
+        const int j = threadIdx.x >> 3, part = threadIdx.x & 7;
+        Best b; b.v = -__builtin_huge_valf(); b.i = 0x7fffffff;
+#pragma unroll 8
+        for (int q = 0; q < HEAD_T / 8; ++q) {
+            const int px = part * (HEAD_T / 8) + q;
+            const float v = vs[px * (JN + 1) + j];
+            if (v > b.v) { b.v = v; b.i = tile * HEAD_T + px; }            // strictly greater: the first maximum of the part
+        }
 #pragma unroll
-        for (int q = 1; q < HEAD_T / 64; ++q) b = better(b, red[q * JN + threadIdx.x]);
-        cand[((size_t)crop * tiles + tile) * JN + threadIdx.x] = b;
+        for (int off = 4; off >= 1; off >>= 1) {
+            Best o; o.v = __shfl_xor(b.v, off, 64); o.i = __shfl_xor(b.i, off, 64);
+            b = better(b, o);
+        }
+        if (part == 0) cand[((size_t)crop * tiles + tile) * JN + j] = b;
     }
 }
 __global__ __launch_bounds__(64) void k_argmax_finish(int tiles, const Best* __restrict__ cand, int hm_h, int hm_w,
@@ -280,7 +288,7 @@ extern "C" int pam_head_decode(void* stream, int n, int hm_h, int hm_w, const vo
         return PAM_E_ARG;
     if (n == 0) return PAM_OK;
     const int HW = hm_h * hm_w, tiles = (HW + HEAD_T - 1) / HEAD_T;
-    const size_t lds = (size_t)J_ * C * sizeof(float) + (size_t)(HEAD_T / 64) * J_ * sizeof(Best);
+    const size_t lds = (size_t)J_ * C * sizeof(float) + (size_t)(HEAD_T / 64) * J_ * sizeof(Best) + (size_t)HEAD_T * (J_ + 1) * sizeof(float);
     hipLaunchKernelGGL((k_head_argmax<PAM_J>), dim3(n * tiles), dim3(HEAD_T), lds, (hipStream_t)stream, HW, tiles,
                        (const uint16_t*)feat_bf16, C, w, bias, dev_heatmaps_or_null, (Best*)dev_scratch);
     hipLaunchKernelGGL(k_argmax_finish, dim3(n), dim3(64), 0, (hipStream_t)stream, tiles, (const Best*)dev_scratch, hm_h, hm_w,

@@ -16,7 +16,7 @@ NUM_JOINTS = 17
 
 class FramePipeline(object):
     def __init__(self, calib_cameras, matcher, conf_threshold, frame_hw, max_dets=8, max_tracks=16, device=0, world=1,
-                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False):
+                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False, net=None):
         """shard: 'views' -- rank owns whole camera views (pose_step / track_step take view-local inputs); 'crops' -- the
         frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices).
         overlap_tracker (crops mode): exchange + tracker kernel + fetch of frame t run on their own stream, under the conv
@@ -32,8 +32,9 @@ class FramePipeline(object):
         self.handle = _lib.Handle(self.C, self.params, max_dets=max_dets, max_tracks=max_tracks, n_scenes=1, device=device)
         self.handle.set_cameras(np.stack([c.P for c in calib_cameras]), np.stack([c.F for c in calib_cameras]),
                                 np.stack([c.RK_INV for c in calib_cameras]), np.stack([c.position for c in calib_cameras]))
-        self.net = HRNetPose(48, 17, None, resolution=(384, 288), device=device, use_graph=use_graph, seed=seed,
-                             max_dets=max_dets) if hrnet else None
+        # net: an existing HRNetPose to share (weights, packed images, captured graphs) between several pipelines of one process
+        self.net = net if net is not None else (HRNetPose(48, 17, None, resolution=(384, 288), device=device, use_graph=use_graph, seed=seed,
+                                                          max_dets=max_dets) if hrnet else None)
         self.shard = shard
         self.gather = ViewGather(self.C, max_dets, world, rank, self.device, group)
         self.crop_gather = CropGather(self.C, max_dets, world, rank, self.device, group) if shard == 'crops' else None
