@@ -326,12 +326,23 @@ static int dispatch_conv(hipStream_t s, const ConvArgs& a, int force) {
 // ====================================================================================================================
 struct C3Args {
     const uint16_t* in; const uint16_t* wimg; const float* bias; const uint16_t* res; uint16_t* out;
-    int N, H, W, Cout, TH, tiles_y, relu, dbg;
+    int N, H, W, Cout, TH, tiles_y, relu;
     float inv_pw;
-    unsigned long long* stamps;      // diagnostic build only (dbg & 64): per-workgroup s_memtime stamps, never read by the kernel
+#ifdef PAM_DIAG
+    int dbg;                         // phase knock-outs / stamps for tools/stamp_conv.py
+    unsigned long long* stamps;      // (dbg & 64): per-workgroup s_memtime stamps, never read by the kernel
+#endif
 };
+// Diagnostic build only (make DIAG=1): phase knock-outs, in-kernel stamps and environment tuning overrides.  The shipped library is
+// compiled without them -- C3_DBG folds to false, C3_STAMP to nothing, no getenv on the launch path.
+#ifdef PAM_DIAG
 static unsigned long long* g_c3_stamps = nullptr;
 extern "C" int pam_conv_debug_stamps(void* dev_buf) { g_c3_stamps = (unsigned long long*)dev_buf; return PAM_OK; }
+#define C3_DBG(bit) (a.dbg & (bit))
+#else
+extern "C" int pam_conv_debug_stamps(void*) { return PAM_E_ARG; }     // kept in the ABI; only the diagnostic build records stamps
+#define C3_DBG(bit) false
+#endif
 // chunk of input channels resident in LDS per K pass: all 48 for Cin = 48 (K walked as the flattened (tap, c) index), 64 for the
 // deep small-image layers (fewer, longer passes hide the load latency), 32 otherwise.  Pitches from tools/lds_sim.py:
 // conflict-free ds_read_b128 needs pitch = 32 (mod 64) bytes for the pixel rows and these row pitches for the weights.
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     constexpr int WIMG = BN * PITCH_W;                                    // bytes of one weight chunk image
     constexpr int NWP = (WIMG / 16 + T - 1) / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (a.dbg & 8) return;
+    if (C3_DBG(8)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
     // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2), so give each XCD a contiguous run of
     // tiles -- vertically adjacent tiles re-read each other's halo rows, which then hit that L2 instead of the fabric
@@ -389,12 +400,16 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
             rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, q < WIMG / 16 ? (unsigned)(q * 16) : OOB_OFFSET, wimg0 + (unsigned)cc * WIMG, 0);
         }
     };
+#ifdef PAM_DIAG
 #define C3_STAMP(k) do { if ((a.dbg & 64) && tid == 0) a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C3_STAMP(k) do { } while (0)
+#endif
     C3_STAMP(0);
     f32x4 bias4[NTW];                                   // lane group g ends with channels n0 + 4*NTW*g + 4*j + r (see the epilogue)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!(a.dbg & 1)) gload_w(0);                       // in flight while the patch descriptors are computed
+    if (!C3_DBG(1)) gload_w(0);                         // in flight while the patch descriptors are computed
 
     // ---- per-thread patch piece descriptors (fixed over the chunk loop) -------------------------------------------------
     unsigned goffA[NPP];
@@ -443,8 +458,8 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     const char* al = smem + (size_t)p_lane * PITCH_A;
     const char* wl = Wsm + (size_t)(lane & 15) * PITCH_W;
 
-    if (a.dbg & 16) { if (goffA[0] == 12345u) a.out[0] = 1; return; }
-    if (!(a.dbg & 1)) gload_a(0);
+    if (C3_DBG(16)) { if (goffA[0] == 12345u) a.out[0] = 1; return; }
+    if (!C3_DBG(1)) gload_a(0);
     C3_STAMP(1);
     if constexpr (NCHUNK == 1) {                        // the slab's only weight chunk is staged once, outside the tile loop
 #pragma unroll
@@ -467,11 +482,11 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     for (int cc = 0; cc < NCHUNK; ++cc) {
         if (cc > 0 || !first) __syncthreads();          // every wave is done reading the previous chunk / tile
         C3_STAMP(2 + 4 * cc);
-        if (!(a.dbg & 32)) lstore(NCHUNK > 1);
+        if (!C3_DBG(32)) lstore(NCHUNK > 1);
         C3_STAMP(3 + 4 * cc);
         __syncthreads();
         C3_STAMP(4 + 4 * cc);
-        if (cc + 1 < NCHUNK && !(a.dbg & 1)) gload(cc + 1);             // next chunk in flight under the MFMAs below
+        if (cc + 1 < NCHUNK && !C3_DBG(1)) gload(cc + 1);               // next chunk in flight under the MFMAs below
         if (cc == NCHUNK - 1 && a.res) {                                // residual tile in flight under the last chunk's MFMAs
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -482,7 +497,7 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
                 c3_row_load<NTW>(rs_res, o, g, rres[i]);
             }
         }
-        if (a.dbg & 2) continue;
+        if (C3_DBG(2)) continue;
         // K loop, software-pipelined by hand: the fragments of step s+1 are read from LDS while the MFMAs of step s issue
         // (with one wave per SIMD nothing else hides the ds_read latency)
         constexpr int NSTEP = (CIN == 48) ? 14 : 9 * (CK / 32);
@@ -530,7 +545,7 @@ __global__ __launch_bounds__(64 * NWAVES, (c3_ck(CIN) == 64 ? 1 : 2)) void k_con
     // lane then holds 4*NTW CONTIGUOUS channels of pixel slot i*16 + (lane & 15) -> residual loads and stores are 16 bytes
     // wide (the store tail is issue-bound), and the 4 lane groups of a pixel cover the slab's 32*NTW contiguous bytes.
     C3_STAMP(60);
-    if (a.dbg & 4) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)acc[0][0][0]; return; }
+    if (C3_DBG(4)) { if (tid == 0) a.out[(size_t)blockIdx.x * 8] = (uint16_t)acc[0][0][0]; return; }
     if (has_next) {     // next TILE's patch goes in flight under this tile's epilogue (the fragment registers are free again by now)
         const int b2 = tile_of(vnext);
         n_nx = b2 / a.tiles_y; ty0_nx = (b2 - n_nx * a.tiles_y) * a.TH;
@@ -601,13 +616,17 @@ static int launch_c3_one(hipStream_t s, const C3Args& a) {
     dim3 grid(a.tiles_y * a.N, a.Cout / (16 * NTW));
     const size_t lds = c3_lds_bytes(CIN, NTW, npatch);
     if (lds > 150 * 1024) return PAM_E_ARG;
-    if (CIN / c3_ck(CIN) == 1 && !(a.dbg & 128)) {      // single-chunk layers: persistent workgroups (see the kernel)
+    if (CIN / c3_ck(CIN) == 1 && !C3_DBG(128)) {        // single-chunk layers: persistent workgroups (see the kernel)
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_conv3x3<CIN, NTW, MT, NWAVES, PMAX>, 64 * NWAVES, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         // One workgroup per CU while a workgroup has only a few tiles to walk: the layer then leaves half of every CU's LDS and
         // registers to the kernels of the other branch streams (measured +2 % on the 20-crop forward; with two per CU the Cin-48
         // chain shuts the other branches out and they run after it).  Large batches fill the chip on their own: all resident slots.
+#ifdef PAM_DIAG
         static const int cap = getenv("PAM_C3_PERSIST_SLOTS") ? atoi(getenv("PAM_C3_PERSIST_SLOTS")) : 0;     // tuning override
+#else
+        constexpr int cap = 0;
+#endif
         int slots = 256 * per_cu / (int)grid.y / 8 * 8;
         const int few = cap > 0 ? cap : ((int)grid.x < 4 * 256 ? 256 : slots);
         if (slots > few) slots = few / 8 * 8;
@@ -653,8 +672,10 @@ extern "C" int pam_conv3x3_slab(int H, int W, int Cin, int Cout) {
     const int wide = (Cout % 48 == 0) ? 48 : 64;
     if (Cin < 192) return wide;
     if (Cout % 48 != 0) return H * W <= 1024 ? 32 : 64;                            // Darknet's 256- / 512-channel 3x3 layers
+#ifdef PAM_DIAG
     const int env = getenv("PAM_C3_SLAB") ? atoi(getenv("PAM_C3_SLAB")) : 0;      // tuning hook
     if (env == 16 || env == 32 || env == 48) return env;
+#endif
     return H * W <= 128 ? 16 : (H * W <= 512 ? 32 : 48);
 }
 
@@ -776,10 +797,14 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.relu = relu; c.inv_pw = 1.0f / (float)(W + 2);
         int cfg = 0;
         pick_rows(N, H, W, Cout, ntw, c.TH, cfg);
+#ifdef PAM_DIAG
         c.dbg = 0; c.stamps = g_c3_stamps;
-        if (tile_cfg >= 100) {                           // test / tuning hook: 100 + dbg bits, or 1000 + TH*100 + cfg
+#endif
+        if (tile_cfg >= 100) {                           // tuning hook: 1000 + TH*100 + cfg (diagnostic build also: 100 + dbg bits)
             if (tile_cfg >= 1000) { c.TH = (tile_cfg - 1000) / 100; cfg = (tile_cfg - 1000) % 100; }
+#ifdef PAM_DIAG
             else c.dbg = tile_cfg - 100;
+#endif
         }
         if (c.TH * (W + 2) > 16 * (cfg / 10) * (cfg % 10)) return PAM_E_ARG;
         c.tiles_y = (H + c.TH - 1) / c.TH;

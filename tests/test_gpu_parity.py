@@ -136,6 +136,19 @@ def test_dlt_vs_oracle_random_masks(lib):
     h.close()
 
 
+@pytest.mark.parametrize('size', ['S1', 'S2'])
+def test_trace_with_the_facades_own_camera_setup(size):
+    """The same golden sequences with NOTHING injected: GetCameraParameters computes the fundamental matrices itself
+    (ivclabpose.py:162-181), so the product's a18 code is on the path the 9-tuple comparison covers."""
+    from pam.ivclabpose import ivclabpose
+
+    def factory(cfg, conf):
+        return ivclabpose(person_detector={'NAME': ''}, pose_detector=None,
+                          person_matcher=dict(cfg, NAME='Iterative'), conf_threshold=conf)
+    n = sum(1 for _ in run_trace(size, factory, atol3d=1e-6, inject_F=False))
+    assert n > 50
+
+
 @pytest.mark.parametrize('size', G.SIZES)
 def test_trace_vs_golden(size):
     """Whole sequences through the drop-in facade: ids, view sets, joints_views, camera ids bit-exact; 3D <= 1e-6 m;

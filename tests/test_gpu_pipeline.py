@@ -47,3 +47,39 @@ def test_crop_mode_matches_view_mode(overlap):
             assert ta['track_id'] == tb['track_id'] and ta['emitted'] == tb['emitted']
             if ta['emitted']:
                 assert np.array_equal(ta['pose3d'], tb['pose3d'])
+
+
+def test_overlap_without_per_frame_sync_matches_serial():
+    """K frames issued back to back with the tracker of frame t on its own stream under frame t + 1 and NO host synchronisation in
+    between (the bench's timed loop): every write to the exchange buffer must be ordered behind the previous frame's readers
+    (FramePipeline.write_send / wait_track).  Final records and every intermediate frame's record equal the serial run's."""
+    from pam import synth
+    from pam.distributed import CropGather
+    from pam.pipeline import FramePipeline
+    seq, cams, cfg, conf, meta = _rig('S2')
+    C, md = meta['C'], 8
+    n_det_all, det_all = synth.pack_frames(seq['frames'], md)
+    ser = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False, shard='crops', overlap_tracker=False)
+    ovl = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False, shard='crops', overlap_tracker=True)
+    dev = ser.device
+    nd = [torch.tensor(n_det_all[t], dtype=torch.int32, device=dev) for t in range(len(seq['frames']))]
+    dd = [torch.tensor(det_all[t], dtype=torch.float64, device=dev) for t in range(len(seq['frames']))]
+    sel = []
+    for t in range(len(seq['frames'])):
+        vl = [v for v in range(C) for _ in range(n_det_all[t][v])]
+        sl = [s for v in range(C) for s in range(n_det_all[t][v])]
+        sel.append(torch.tensor(CropGather.select_index(vl, sl, C, md, 1)[0], dtype=torch.int64, device=dev))
+    # a long kernel on the pose stream in front of every frame keeps the tracker stream behind, as the conv stack does in the bench
+    ballast = torch.randn((4096, 4096), device=dev)
+    recs = []
+    for t in range(len(seq['frames'])):
+        ser.write_send(dd[t]); ser.track_step_crops(t, nd[t], sel[t])
+        recs.append(ser.results())
+    for t in range(len(seq['frames'])):
+        _ = ballast @ ballast
+        ovl.write_send(dd[t]); ovl.track_step_crops(t, nd[t], sel[t])
+    last = ovl.results()
+    assert last['n_tracks'] == recs[-1]['n_tracks'] and last['frame_id'] == recs[-1]['frame_id']
+    for ta, tb in zip(recs[-1]['tracks'], last['tracks']):
+        assert ta['track_id'] == tb['track_id'] and ta['hits'] == tb['hits'] and ta['age'] == tb['age'] and ta['emitted'] == tb['emitted']
+        assert np.array_equal(ta['pose3d'], tb['pose3d']) and np.array_equal(ta['velocity'], tb['velocity'])

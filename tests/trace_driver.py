@@ -7,7 +7,7 @@ from pam import synth
 import golden_io as G
 
 
-def run_trace(size, factory, atol3d=1e-7):
+def run_trace(size, factory, atol3d=1e-7, inject_F=True):
     """Drive a façade over a golden trace exactly as testmodel.py does; yield per-frame comparisons."""
     tr = G.load('trace_%s.npz' % size)
     c = G.cameras(size)
@@ -15,7 +15,8 @@ def run_trace(size, factory, atol3d=1e-7):
     cfg = dict(synth.MATCHER_CFG[dataset])
     conf = cfg.pop('CONF_THRESHOLD')
     model = factory(cfg, conf)
-    model.GetCameraParameters({'P': c['P'], 'K': c['K'], 'RT': c['RT']}, 0, 0, F=c['F'])
+    # inject_F=False: the facade's own camera set-up (fundamental matrices included) is on the tested path
+    model.GetCameraParameters({'P': c['P'], 'K': c['K'], 'RT': c['RT']}, 0, 0, **({'F': c['F']} if inject_F else {}))
     frames = G.trace_frames(tr)
     skipped = set(tr['meta.skipped'].tolist())
     C = len(frames[0])

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""In-kernel phase stamps of k_conv3x3 (diagnostic; dbg bit 64)."""
+"""NEEDS THE DIAGNOSTIC LIBRARY: `make -C <package>/csrc clean && make -C <package>/csrc DIAG=1` (the shipped build has no stamp code).
+In-kernel phase stamps of k_conv3x3 (diagnostic; dbg bit 64)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.nn as nn
