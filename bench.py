@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default=None, choices=['S1', 'S2', 'S3', 'S4'], help='default: S2 on one GPU, S4 on several')
     ap.add_argument('--shard', default=None, choices=['views', 'crops'], help='default: crops on one GPU (= no exchange), views on several')
+    ap.add_argument('--exchange', default='torch', choices=['torch', 'abi'], help="abi: the all-gather through pam_allgather_keypoints (RCCL called by the library; view sharding, real multi-GPU only)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-batched', action='store_true')
     ap.add_argument('--no-families', action='store_true')
@@ -230,7 +231,8 @@ def main():
     max_dets = 8
     overlap = (not args.no_overlap) and shard == 'crops'
     pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
-                         rank=rank, use_graph=not args.no_graph, shard=shard, overlap_tracker=overlap)
+                         rank=rank, use_graph=not args.no_graph, shard=shard, overlap_tracker=overlap,
+                         exchange=args.exchange if (shard == 'views' and not single_dev) else 'torch')
     inp = build_inputs(torch, synth, seq, size, max_dets, world, rank, shard, dev, nF)
     torch.cuda.synchronize()
 
@@ -272,7 +274,7 @@ def main():
                        'views_per_rank': [len(p) for p in view_partition(C, world)] if shard == 'views' else None,
                        'tracker': 'fused HIP frame kernel (f64), replicated after the exchange', 'hrnet_weights': pipe.net.weights if pipe.net else None,
                        'conv_backend': pipe.net.backend if pipe.net else None,
-                       'exchange': ('one all_gather_into_tensor per frame (%s)' % backend) if world > 1 else 'none',
+                       'exchange': ('one all-gather per frame (%s)' % ('pam_allgather_keypoints: RCCL called inside the C ABI' if pipe.comm else 'torch.distributed ' + backend)) if world > 1 else 'none',
                        'devices': '%d ranks on ONE device (no multi-GPU box: functional check only)' % world if single_dev and world > 1 else '%d' % world},
             'roofline': {'kernel': 'HRNet-W48 conv stack: k_bblock / k_conv3x3 / k_conv_igemm / k_upsample_add (hipGraph replay, %d crops, %d launches)'
                                    % (n_med, launches),

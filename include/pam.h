@@ -224,6 +224,19 @@ int pam_basic_block_nhwc_bf16(void* stream, int n_branches, const PamBlockDesc* 
 /* waves: 4 = 256-thread workgroups, two per CU (C = 48 / 96 only), 8 = 512-thread workgroups, 0 = 4 when every branch allows it */
 int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* blocks, int waves);
 
+/* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
+ * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before
+ * the cross-view match every rank contributes its views' keypoint records and receives everyone's: ONE all-gather per frame, enqueued on
+ * the stream the decode ran on.  Record per view: [n_det, det[max_dets*17*3]] float64 (rows (y, x, score)); rows_per_rank = the largest
+ * number of views any rank owns (unused rows are padding); dev_recv holds world * rows_per_rank records, rank-major.
+ * The communicator is RCCL's (ncclComm_t); librccl is bound at run time, so single-GPU hosts never need it.  pam_comm_unique_id on one
+ * rank -> ship the 128 bytes to the others by any means -> pam_comm_init on every rank (collective). */
+int pam_comm_unique_id(void* id128);
+int pam_comm_init(void** comm, int world, int rank, const void* id128, int device);
+int pam_comm_destroy(void* comm);
+const char* pam_comm_last_error(void);
+int pam_allgather_keypoints(PamHandle* h, void* comm, void* stream, const double* dev_send, int rows_per_rank, double* dev_recv);
+
 /* ---- grouped launches for the HRNet fuse layers (row a1): several small independent convolutions / several fuse sums in ONE
  * launch each -- a fuse layer is ~10 kernels of 10-40 us whose launch chain, not their arithmetic, is what takes time.
  * pam_conv2d_group_nhwc_bf16: up to 8 convolutions with the arguments of pam_conv2d_nhwc_bf16_ex (Cout % 48 == 0, relu 0 / 1);

@@ -94,6 +94,11 @@ _SIGS = {
     'pam_basic_block_chunk_layout': (_I, [_I, _P]),
     'pam_basic_block_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_basic_block_nhwc_bf16_ex': (_I, [_P, _I, _P, _I]),
+    'pam_comm_unique_id': (_I, [_P]),
+    'pam_comm_init': (_I, [C.POINTER(_P), _I, _I, _P, _I]),
+    'pam_comm_destroy': (_I, [_P]),
+    'pam_comm_last_error': (C.c_char_p, []),
+    'pam_allgather_keypoints': (_I, [_P, _P, _P, _P, _I, _P]),
     'pam_conv2d_group_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_upsample_add_group_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_head_decode_scratch_bytes': (C.c_longlong, [_I, _I, _I]),

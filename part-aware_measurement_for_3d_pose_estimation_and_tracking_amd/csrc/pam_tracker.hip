@@ -1097,3 +1097,70 @@ extern "C" int pam_op_hyp_cost(PamHandle* h, int n_members, const int32_t* cids,
     S.back(cost, oc, 1); S.back(veto, ov, 1);
     return S.ok ? PAM_OK : PAM_E_HIP;
 }
+
+// ---- row e: the ONE exchange of the path, inside the C ABI --------------------------------------------------------------------
+// pam_allgather_keypoints enqueues an RCCL all-gather of this rank's per-view keypoint records on the caller's (decode) stream, so a
+// host that is not PyTorch can run the sharded path with nothing but this library.  RCCL is bound at run time (dlopen of
+// librccl.so.1: the process may already carry PyTorch's copy, which then serves these calls too); single-GPU users never load it.
+#include <dlfcn.h>
+struct Id128 { char b[128]; };                          // ncclUniqueId (passed by value to ncclCommInitRank)
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+static RcclApi g_rccl;
+static std::string g_rccl_err;
+static bool rccl_load() {
+    if (g_rccl.lib) return true;
+    void* l = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!l) l = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!l) { g_rccl_err = std::string("dlopen librccl: ") + dlerror(); return false; }
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(l, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(l, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(l, "ncclCommDestroy");
+    g_rccl.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(l, "ncclAllGather");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(l, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) { g_rccl_err = "librccl lacks the nccl* entry points"; dlclose(l); return false; }
+    g_rccl.lib = l;
+    return true;
+}
+#define RCCLCHK(call) do { int e_ = (call); if (e_ != 0) { g_rccl_err = std::string(#call) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e_) : "error"); \
+    return PAM_E_HIP; } } while (0)
+
+extern "C" const char* pam_comm_last_error(void) { return g_rccl_err.c_str(); }
+extern "C" int pam_comm_unique_id(void* id128) {
+    if (!id128) return PAM_E_ARG;
+    if (!rccl_load()) return PAM_E_STATE;
+    RCCLCHK(g_rccl.GetUniqueId(id128));
+    return PAM_OK;
+}
+extern "C" int pam_comm_init(void** comm, int world, int rank, const void* id128, int device) {
+    if (!comm || !id128 || world < 1 || rank < 0 || rank >= world) return PAM_E_ARG;
+    if (!rccl_load()) return PAM_E_STATE;
+    if (hipSetDevice(device) != hipSuccess) { g_rccl_err = "hipSetDevice failed"; return PAM_E_HIP; }
+    Id128 id; memcpy(id.b, id128, 128);
+    RCCLCHK(g_rccl.CommInitRank(comm, world, id, rank));
+    return PAM_OK;
+}
+extern "C" int pam_comm_destroy(void* comm) {
+    if (!comm) return PAM_OK;
+    if (!rccl_load()) return PAM_E_STATE;
+    RCCLCHK(g_rccl.CommDestroy(comm));
+    return PAM_OK;
+}
+extern "C" int pam_allgather_keypoints(PamHandle* h, void* comm, void* stream, const double* dev_send, int rows_per_rank, double* dev_recv) {
+    if (!h) return PAM_E_ARG;
+    ARGCHK(h, comm && dev_send && dev_recv && rows_per_rank >= 1, "null communicator / buffer");
+    if (!rccl_load()) { h->err = g_rccl_err; return PAM_E_STATE; }
+    // one record per view: [n_det, det[max_dets * 17 * 3]] float64 (ViewGather's layout); ncclFloat64 = 8
+    const size_t count = (size_t)rows_per_rank * (1 + (size_t)h->d.MAXP * J3);
+    const int e = g_rccl.AllGather(dev_send, dev_recv, count, 8 /* ncclFloat64 */, comm, (hipStream_t)stream);
+    if (e != 0) { h->err = std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return PAM_E_HIP; }
+    return PAM_OK;
+}

@@ -19,12 +19,43 @@ def view_partition(n_views, world):
     return [[v for v in range(n_views) if v * world // n_views == r] for r in range(world)]
 
 
+class AbiComm(object):
+    """RCCL communicator owned through the C ABI (pam_comm_*): what a host without PyTorch would hold.  The 128-byte unique id is
+    made on rank 0 and shipped with whatever the host has -- here a torch.distributed broadcast (any backend) when world > 1."""
+
+    def __init__(self, world, rank, device_index, group=None):
+        import ctypes as C
+        from . import _lib
+        self.lib = _lib.load()
+        idb = (C.c_char * 128)()
+        if rank == 0:
+            rc = self.lib.pam_comm_unique_id(C.cast(idb, C.c_void_p))
+            if rc != 0:
+                raise _lib.PamError('pam_comm_unique_id failed (%d): %s' % (rc, self.lib.pam_comm_last_error().decode()))
+        if world > 1:
+            box = [bytes(idb.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            idb.raw = box[0]
+        self.comm = C.c_void_p()
+        rc = self.lib.pam_comm_init(C.byref(self.comm), world, rank, C.cast(idb, C.c_void_p), device_index)
+        if rc != 0:
+            raise _lib.PamError('pam_comm_init failed (%d): %s' % (rc, self.lib.pam_comm_last_error().decode()))
+
+    def close(self):
+        if self.comm:
+            self.lib.pam_comm_destroy(self.comm)
+            self.comm = None
+
+
 class ViewGather(object):
     """Fixed-size padded record per view: [n_det, det[max_dets*17*3]] float64 (float64 keeps caller-supplied keypoints
     lossless; records decoded from float32 heat-maps are exactly representable)."""
 
-    def __init__(self, n_views, max_dets, world, rank, device, group=None):
+    def __init__(self, n_views, max_dets, world, rank, device, group=None, abi=None):
+        """abi: (Handle, AbiComm) -> the exchange goes through pam_allgather_keypoints (RCCL called from the library, enqueued on the
+        current stream) instead of torch.distributed."""
         self.C, self.max_dets, self.world, self.rank, self.group = n_views, max_dets, world, rank, group
+        self.abi = abi
         self.parts = view_partition(n_views, world)
         self.mine = self.parts[rank]
         self.maxv = max(1, max(len(p) for p in self.parts))
@@ -46,7 +77,15 @@ class ViewGather(object):
         if k:
             self.send[:k, 0] = n_det_local.to(torch.float64)
             self.send[:k, 1:] = det_local.reshape(k, -1)
-        if self.world > 1:
+        if self.abi is not None:
+            import ctypes as C
+            handle, comm = self.abi
+            rc = handle.lib.pam_allgather_keypoints(handle.raw, comm.comm, C.c_void_p(torch.cuda.current_stream(self.send.device).cuda_stream),
+                                                    C.c_void_p(self.send.data_ptr()), self.maxv, C.c_void_p(self.recv.data_ptr()))
+            if rc != 0:
+                raise RuntimeError('pam_allgather_keypoints failed (%d): %s' % (rc, handle.lib.pam_last_error(handle.raw).decode()))
+            full = self.recv.index_select(0, self.rows)
+        elif self.world > 1:
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
             full = self.recv.index_select(0, self.rows)
         else:

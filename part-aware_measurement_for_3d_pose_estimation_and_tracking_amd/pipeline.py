@@ -16,7 +16,7 @@ NUM_JOINTS = 17
 
 class FramePipeline(object):
     def __init__(self, calib_cameras, matcher, conf_threshold, frame_hw, max_dets=8, max_tracks=16, device=0, world=1,
-                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False, net=None):
+                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False, net=None, exchange='torch'):
         """shard: 'views' -- rank owns whole camera views (pose_step / track_step take view-local inputs); 'crops' -- the
         frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices).
         overlap_tracker (crops mode): exchange + tracker kernel + fetch of frame t run on their own stream, under the conv
@@ -36,7 +36,13 @@ class FramePipeline(object):
         self.net = net if net is not None else (HRNetPose(48, 17, None, resolution=(384, 288), device=device, use_graph=use_graph, seed=seed,
                                                           max_dets=max_dets) if hrnet else None)
         self.shard = shard
-        self.gather = ViewGather(self.C, max_dets, world, rank, self.device, group)
+        # exchange: 'torch' = torch.distributed (RCCL when the backend is nccl, gloo in the CPU tests); 'abi' = pam_allgather_keypoints,
+        # the library's own RCCL call on the decode stream (view sharding only)
+        self.comm = None
+        if exchange == 'abi':
+            from .distributed import AbiComm
+            self.comm = AbiComm(world, rank, device, group)
+        self.gather = ViewGather(self.C, max_dets, world, rank, self.device, group, abi=(self.handle, self.comm) if self.comm else None)
         self.crop_gather = CropGather(self.C, max_dets, world, rank, self.device, group) if shard == 'crops' else None
         self.mine = self.gather.mine
         # decode target: this rank's views only, (len(mine), max_dets, 17, 3)

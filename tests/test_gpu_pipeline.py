@@ -83,3 +83,29 @@ def test_overlap_without_per_frame_sync_matches_serial():
     for ta, tb in zip(recs[-1]['tracks'], last['tracks']):
         assert ta['track_id'] == tb['track_id'] and ta['hits'] == tb['hits'] and ta['age'] == tb['age'] and ta['emitted'] == tb['emitted']
         assert np.array_equal(ta['pose3d'], tb['pose3d']) and np.array_equal(ta['velocity'], tb['velocity'])
+
+
+def test_allgather_keypoints_through_the_c_abi():
+    """pam_comm_* + pam_allgather_keypoints on a one-rank communicator (a single-GPU box cannot hold two RCCL ranks): the record
+    rows come back unchanged, and a FramePipeline whose exchange runs through the C ABI tracks exactly like the torch one."""
+    import ctypes as C
+    from pam import synth, _lib
+    from pam.distributed import AbiComm
+    from pam.pipeline import FramePipeline
+    seq, cams, cfg, conf, meta = _rig('S1')
+    Cn, md = meta['C'], 8
+    n_det_all, det_all = synth.pack_frames(seq['frames'], md)
+    ref = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False)
+    abi = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False, exchange='abi')
+    assert abi.comm is not None and abi.gather.abi is not None
+    dev = ref.device
+    for t in range(len(seq['frames'])):
+        nd = torch.tensor(n_det_all[t], dtype=torch.int32, device=dev)
+        dd = torch.tensor(det_all[t], dtype=torch.float64, device=dev)
+        ref.track_step(t, nd, dd); a = ref.results()
+        abi.track_step(t, nd, dd); b = abi.results()
+        assert torch.equal(abi.gather.recv[:Cn], abi.gather.send[:Cn])
+        assert a['n_tracks'] == b['n_tracks']
+        for ta, tb in zip(a['tracks'], b['tracks']):
+            assert ta['track_id'] == tb['track_id'] and ta['emitted'] == tb['emitted'] and np.array_equal(ta['pose3d'], tb['pose3d'])
+    abi.comm.close()
