@@ -373,44 +373,50 @@ def hbm_traffic(n_crops, launches):
 
 
 def conv_families(torch, net, n, stack_ms):
-    """Per-kernel-family roofline of the conv stack: ONE eager forward on a single stream with HIP events around every launch (each
-    kernel alone on the chip), 3 repetitions averaged.  bound: 'mfma' / 'hbm' = the roof the family is closer to; 'latency' when it
-    reaches < 10 % of both (launch chain / occupancy bound: too few, too short workgroups)."""
+    """Per-kernel-family roofline of the conv stack.  One eager forward records every launch (a closure that re-issues exactly that
+    launch); each DISTINCT launch (family + shapes) is then timed alone on the chip: 20 back-to-back repetitions between two HIP
+    events, i.e. kernel time incl. one dependent launch boundary.  bound: 'mfma' / 'hbm' = the roof the family is closer to;
+    'latency' when it reaches < 10 % of both (too few, too short workgroups: launch-chain / occupancy bound)."""
     hip = net.hip
     x = net.input_buffer(n)
     saved = (hip.multi_stream, hip.prof)
     hip.multi_stream = False
-    reps = 3
-    runs = []
     try:
         with torch.no_grad():
-            hip.prof = None
-            hip.features(x); torch.cuda.synchronize()
-            for _ in range(reps):
-                hip.prof = []
-                hip.features(x)
-                torch.cuda.synchronize()
-                runs.append([(p['family'], p['bytes'], p['flops'], p['ev'][0].elapsed_time(p['ev'][1])) for p in hip.prof])
+            hip.prof = []
+            hip.features(x)
+            torch.cuda.synchronize()
+            rec = hip.prof
     finally:
         hip.multi_stream, hip.prof = saved
+    t_sig = {}
+    for r in rec:
+        if r['sig'] in t_sig:
+            continue
+        r['fn'](); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            r['fn']()
+        b.record(); torch.cuda.synchronize()
+        t_sig[r['sig']] = a.elapsed_time(b) / 20.0            # ms
     agg = {}
-    for run in runs:
-        for fam, by, fl, ms in run:
-            a = agg.setdefault(fam, dict(launches=0, bytes=0, flops=0, ms=0.0))
-            a['launches'] += 1; a['bytes'] += by; a['flops'] += fl; a['ms'] += ms
+    for r in rec:
+        g = agg.setdefault(r['family'], dict(launches=0, bytes=0, flops=0, ms=0.0))
+        g['launches'] += 1; g['bytes'] += r['bytes']; g['flops'] += r['flops']; g['ms'] += t_sig[r['sig']]
     fams = []
-    for fam, a in agg.items():
-        L, by, fl, ms = a['launches'] / reps, a['bytes'] / reps, a['flops'] / reps, a['ms'] / reps
+    for fam, g in agg.items():
+        L, by, fl, ms = g['launches'], g['bytes'], g['flops'], g['ms']
         gbs, tfs = by / (ms * 1e-3) / 1e9, fl / (ms * 1e-3) / 1e12
         fh, fm = gbs / HBM_PEAK_GBS, tfs / MFMA_BF16_PEAK_TFLOPS
         bound = 'latency' if max(fh, fm) < 0.10 else ('mfma' if fm >= fh else 'hbm')
-        fams.append({'kernel': fam, 'launches': int(round(L)), 'us_per_launch': ms * 1e3 / L, 'us_total': ms * 1e3,
+        fams.append({'kernel': fam, 'launches': L, 'us_per_launch': ms * 1e3 / L, 'us_total': ms * 1e3,
                      'algorithmic_bytes': int(by), 'flops': int(fl), 'bound': bound, 'frac': max(fh, fm),
                      'hbm_frac': fh, 'mfma_frac': fm, 'achieved_GBs': gbs, 'achieved_TFLOPs': tfs})
     fams.sort(key=lambda f: -f['us_total'])
     serial = sum(f['us_total'] for f in fams) * 1e-3
-    return {'families': fams, 'note': 'each kernel alone on the chip (eager, one stream, HIP events per launch); sum %.3f ms vs %.3f ms for the '
-                                      'multi-stream hipGraph replay of the same forward' % (serial, stack_ms)}
+    return {'families': fams, 'note': 'each distinct launch alone on the chip (20 back-to-back repetitions between HIP events); sum over the '
+                                      'forward %.3f ms vs %.3f ms for the multi-stream hipGraph replay of the same forward' % (serial, stack_ms)}
 
 
 def surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, K, W):

@@ -92,7 +92,7 @@ __device__ __forceinline__ void c3_row_store(uint16_t* p, int g, const uint32_t*
 template <int NTW, int WM, int WN, bool GEN>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx, const int by) {
     constexpr int T = 64 * WM * WN, BM = 64 * WM, BN = 16 * NTW * WN;
-    constexpr int APT = BM * 8 / T;                    // A pieces (16 B) per thread per chunk
+    constexpr int APT = (BM * 8 + T - 1) / T;          // A pieces (16 B) per thread per chunk (the last pass is partial when T does not divide BM * 8)
     constexpr int BPT = (BN * 8 + T - 1) / T;          // B pieces per thread per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                                   // [2][BM][ROWB]
@@ -112,7 +112,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx,
         const int row = (tid >> 3) + i * (T / 8);
         const int m = m0 + row;
         rowoff[i] = 0; tapmask[i] = 0;
-        if (m < a.M) {
+        if (m < a.M && row < BM) {
             const int hw = a.Ho * a.Wo;
             const int n = m / hw, r = m - n * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
             const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
@@ -157,7 +157,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx,
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int row = (tid >> 3) + i * (T / 8);
-            *(u32x4*)(As + (size_t)buf * BM * ROWB + row * ROWB + kq * 16) = areg[i];
+            if (BM * 8 % T == 0 || row < BM) *(u32x4*)(As + (size_t)buf * BM * ROWB + row * ROWB + kq * 16) = areg[i];
         }
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
@@ -301,7 +301,11 @@ static int dispatch_conv(hipStream_t s, const ConvArgs& a, int force) {
     auto blocks = [&](int wm, int wn) { return (long)((a.M + 64 * wm - 1) / (64 * wm)) * (nb / wn); };
     int cfg = force;
     if (cfg < 0) {                                      // measured per HRNet layer shape with tools/bench_conv.py --tiles=...
-        if (nb % 2 == 0) cfg = blocks(2, 2) >= 400 ? 3 : 1;   // two N tiles per workgroup: the input tile is staged once for both
+        // 48-wide N tiles, 3 or 4 of them: the whole layer per pixel tile, the gathered input staged ONCE (merged fuse-layer heads
+        // 48 -> 144 / 192, stride 2: 33.6 -> 25.4 us, 28.5 -> 25.9 us at 20 crops; 6 tiles: no gain over two workgroups of 3)
+        if (NTW == 3 && nb == 3) cfg = 5;
+        else if (NTW == 3 && nb == 4) cfg = 6;
+        else if (nb % 2 == 0) cfg = blocks(2, 2) >= 400 ? 3 : 1;   // two N tiles per workgroup: the input tile is staged once for both
         else cfg = blocks(2, 1) >= 512 ? 2 : 0;
     }
     switch (cfg) {
@@ -310,6 +314,9 @@ static int dispatch_conv(hipStream_t s, const ConvArgs& a, int force) {
         case 2: return launch_conv<NTW, 2, 1>(s, a);
         case 3: return (nb % 2) ? PAM_E_ARG : launch_conv<NTW, 2, 2>(s, a);
         case 4: return launch_conv<NTW, 4, 1>(s, a);
+        case 5: return (nb % 3) ? PAM_E_ARG : launch_conv<NTW, 1, 3>(s, a);     // all of a 144- / 192-channel layer per pixel tile: input staged once
+        case 6: return (nb % 4) ? PAM_E_ARG : launch_conv<NTW, 1, 4>(s, a);
+        case 7: return (nb % 3) ? PAM_E_ARG : launch_conv<NTW, 2, 3>(s, a);
     }
     return PAM_E_ARG;
 }

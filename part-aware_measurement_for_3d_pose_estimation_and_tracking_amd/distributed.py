@@ -133,3 +133,21 @@ class CropGather(object):
             torch.index_select(self.recv.view(self.world * self.rows, -1), 0, select, out=self.det.view(self.rows, -1))
             return self.det
         return self.send
+
+
+def gather_crop_keypoints(kp_local, n_total, world, rank, group=None):
+    """The drop-in surface's exchange (HRNetPose.predict under torch.distributed): the call's n_total person crops are dealt out with
+    ``crop_partition``; every rank decodes its share -> kp_local (b - a, 17, 3) float32 (x, y, score) -> ONE all-gather ->
+    (n_total, 17, 3), identical on every rank.  Works on CPU tensors (gloo) and CUDA tensors (RCCL)."""
+    parts = crop_partition(n_total, world)
+    if world == 1:
+        return kp_local
+    maxn = max(1, max(b - a for a, b in parts))
+    send = torch.zeros((maxn, NUM_JOINTS, 3), dtype=kp_local.dtype, device=kp_local.device)
+    a, b = parts[rank]
+    if b > a:
+        send[:b - a] = kp_local
+    recv = torch.empty((world * maxn, NUM_JOINTS, 3), dtype=kp_local.dtype, device=kp_local.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    idx = torch.tensor([r * maxn + i for r, (p, q) in enumerate(parts) for i in range(q - p)], dtype=torch.long, device=kp_local.device)
+    return recv.index_select(0, idx)

@@ -240,6 +240,17 @@ class HRNetPose(object):
         if not torch.cuda.is_available():
             raise RuntimeError('HRNetPose needs a GPU (the preprocessing / decode kernels are HIP only; no CPU fallback)')
         self.lib = _lib.load()
+        # hrpose_args: the reference hands HRNetPose every visible GPU (gpu_args.gpus / .device, ivclabpose.py:107-111,131-132) and
+        # lets the backend spread a batch over them inside one process.  Here the unit is one process per GPU: under an initialised
+        # torch.distributed group of W ranks, predict() deals the call's person crops out over the ranks, runs its share on ITS
+        # device (hrpose_args.device if given, else `device`), and ONE all-gather returns every rank the complete dump.
+        import torch.distributed as dist
+        self.world, self.rank = (dist.get_world_size(), dist.get_rank()) if (dist.is_available() and dist.is_initialized()) else (1, 0)
+        dv = getattr(hrpose_args, 'device', None) if hrpose_args is not None else None
+        if dv is None and isinstance(hrpose_args, dict):
+            dv = hrpose_args.get('device')
+        if dv is not None and torch.device(dv).type == 'cuda' and torch.device(dv).index is not None:
+            device = torch.device(dv).index
         self.device = torch.device('cuda:%d' % device)
         self.resolution = tuple(resolution)
         self.dtype = dtype
@@ -424,8 +435,12 @@ class HRNetPose(object):
         ptrs = m[o_ptr:].view(torch.int64)
         det = torch.empty((V, max(self.max_dets, max(cnt)), 17, 3), dtype=torch.float64, device=self.device)
         kp = torch.empty((n, 17, 3), dtype=torch.float32, device=self.device)
-        for s in range(0, n, batch_size):
-            e = min(n, s + batch_size)
+        lo, hi = 0, n
+        if self.world > 1:                                # this rank's share of the call's crops (ordered by view, then person)
+            from .distributed import crop_partition
+            lo, hi = crop_partition(n, self.world)[self.rank]
+        for s in range(lo, hi, batch_size):
+            e = min(hi, s + batch_size)
             k = e - s
             mp = min(batch_size, (k + self.graph_bucket - 1) // self.graph_bucket * self.graph_bucket) if batch_size >= self.graph_bucket else k
             vo, bb = view_of[s:e], bx[s:e]
@@ -437,6 +452,11 @@ class HRNetPose(object):
                 self.head_decode(self.features(x), view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e], n=k)
             else:
                 self.decode(self.heatmaps(x)[:k], view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
+        if self.world > 1:
+            from .distributed import gather_crop_keypoints
+            kp = gather_crop_keypoints(kp[lo:hi].contiguous(), n, self.world, self.rank)
+            # the tracker's device-side input, rebuilt from the gathered rows: (view, slot) <- (y, x, score) as float64
+            det[view_of.long(), slot_of.long()] = kp[:, :, [1, 0, 2]].double()
         kp_h = kp.cpu().numpy().astype(np.float64)       # the reference's contract is host lists: one device -> host copy per call
         flat = kp_h.reshape(n, 51).tolist()
         score = kp_h[:, :, 2].tolist()

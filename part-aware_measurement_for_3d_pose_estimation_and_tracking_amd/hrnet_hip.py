@@ -130,21 +130,12 @@ class PackedBlock(object):
 class ConvEngine(object):
     """Kernel launchers shared by the pose network (HipHRNet) and the person detector (yolov3.HipDarknet)."""
     count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
-    prof = None             # set to a list: every launch appends dict(family, bytes, flops, ev=(start, end)) (bench.py: per-family roofline)
+    prof = None             # set to a list: every launch appends dict(family, sig, bytes, flops, fn) -- fn re-issues exactly that launch
+                            # (bench.py times each distinct one alone for the per-family roofline)
 
-    def _prof_begin(self, x):
-        if self.prof is None or x.device.type != 'cuda':
-            return None
-        a = torch.cuda.Event(enable_timing=True)
-        a.record(torch.cuda.current_stream(x.device))
-        return a
-
-    def _prof_end(self, a, x, family, nbytes, flops):
-        if a is None:
-            return
-        b = torch.cuda.Event(enable_timing=True)
-        b.record(torch.cuda.current_stream(x.device))
-        self.prof.append(dict(family=family, bytes=nbytes, flops=flops, ev=(a, b)))
+    def _prof_add(self, x, family, sig, nbytes, flops, fn):
+        if self.prof is not None and x.device.type == 'cuda':
+            self.prof.append(dict(family=family, sig=(family,) + tuple(sig), bytes=nbytes, flops=flops, fn=fn))
     tile_cfg = -1
     _keep = None
     ACT = {None: 0, False: 0, True: 1, 'linear': 0, 'relu': 1, 'leaky': 2}
@@ -169,23 +160,24 @@ class ConvEngine(object):
         act = self.ACT[relu] | (4 if (res_after_act and res is not None) else 0)
         wimg = op.image(h, w) if (in_cs == cin and relu_from == 0) else None
         st = torch.cuda.current_stream(x.device).cuda_stream
-        pa = self._prof_begin(x)
-        rc = self.lib.pam_conv2d_nhwc_bf16_ex(C.c_void_p(st), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
-                                              C.c_void_p(wimg.data_ptr()) if wimg is not None else None,
-                                              C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
-                                              C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad,
-                                              act, self.tile_cfg, in_cs, relu_from)
+        launch = lambda: self.lib.pam_conv2d_nhwc_bf16_ex(
+            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
+            C.c_void_p(wimg.data_ptr()) if wimg is not None else None,
+            C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
+            C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad, act, self.tile_cfg, in_cs, relu_from)
+        rc = launch()
         if rc != 0:
             raise _lib.PamError('pam_conv2d_nhwc_bf16 failed (%d) for %s' % (rc, (x.shape, op.cout, op.kh, op.stride)))
-        if pa is not None:
+        if self.prof is not None:
             if op._stem is not None:
                 fam = 'k_conv_stem %d->%d' % (3, op.cout)
             elif wimg is not None:
                 fam = 'k_conv3x3 C=%d %dx%d' % (op.cin, h, w)
             else:
                 fam = 'k_conv_igemm %dx%d stride %d' % (op.kh, op.kw, op.stride)
-            self._prof_end(pa, x, fam, 2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin + (y.numel() if res is not None else 0)) + 4 * op.cout,
-                           2 * y.numel() * op.kh * op.kw * op.cin)
+            self._prof_add(x, fam, (n, h, w, op.cin, op.cout, res is not None, in_cs, relu_from),
+                           2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin + (y.numel() if res is not None else 0)) + 4 * op.cout,
+                           2 * y.numel() * op.kh * op.kw * op.cin, launch)
         return y
 
     def basic_blocks(self, ops, xs, waves=0):
@@ -210,14 +202,14 @@ class ConvEngine(object):
             self.count['launches'] += 1
         if xs[0].device.type == 'meta':
             return ys
-        st = torch.cuda.current_stream(xs[0].device).cuda_stream
-        pa = self._prof_begin(xs[0])
-        rc = self.lib.pam_basic_block_nhwc_bf16_ex(C.c_void_p(st), len(ops), C.cast(descs, C.c_void_p), waves)
+        launch = lambda: self.lib.pam_basic_block_nhwc_bf16_ex(C.c_void_p(torch.cuda.current_stream(xs[0].device).cuda_stream), len(ops),
+                                                                C.cast(descs, C.c_void_p), waves)
+        rc = launch()
         if rc != 0:
             raise _lib.PamError('pam_basic_block_nhwc_bf16 failed (%d) for %s' % (rc, [tuple(x.shape) for x in xs]))
-        self._prof_end(pa, xs[0], 'k_bblock C=' + '+'.join(str(o.c) for o in ops),
+        self._prof_add(xs[0], 'k_bblock C=' + '+'.join(str(o.c) for o in ops), tuple(tuple(x.shape) for x in xs),
                        sum(2 * (2 * x.numel() + 2 * 9 * o.c * o.c) + 8 * o.c for o, x in zip(ops, xs)),
-                       sum(2 * 2 * x.numel() * 9 * o.c for o, x in zip(ops, xs)))
+                       sum(2 * 2 * x.numel() * 9 * o.c for o, x in zip(ops, xs)), launch)
         return ys
 
     def upsample_add(self, base, terms, shifts, relu):
@@ -234,12 +226,13 @@ class ConvEngine(object):
         ptrs = (C.c_void_p * 3)(*[C.c_void_p(t.data_ptr()) for t in terms] + [None] * (3 - len(terms)))
         sh = (C.c_int32 * 3)(*(list(shifts) + [0] * (3 - len(shifts))))
         cs = (C.c_int32 * 3)(*([t.stride(3) for t in terms] + [0] * (3 - len(terms))))       # terms may be channel slices
-        pa = self._prof_begin(base)
-        rc = self.lib.pam_upsample_add_nhwc_bf16_ex(C.c_void_p(st), C.c_void_p(base.data_ptr()), len(terms), ptrs, sh, cs,
-                                                    C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0)
+        launch = lambda: self.lib.pam_upsample_add_nhwc_bf16_ex(C.c_void_p(torch.cuda.current_stream(base.device).cuda_stream),
+                                                                 C.c_void_p(base.data_ptr()), len(terms), ptrs, sh, cs,
+                                                                 C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0)
+        rc = launch()
         if rc != 0:
             raise _lib.PamError('pam_upsample_add_nhwc_bf16 failed (%d)' % rc)
-        self._prof_end(pa, base, 'k_upsample_add', 2 * (2 * base.numel() + sum(t.numel() for t in terms)), 0)
+        self._prof_add(base, 'k_upsample_add', (n, h, w, c, len(terms)), 2 * (2 * base.numel() + sum(t.numel() for t in terms)), 0, launch)
         return y
 
     def conv_group(self, specs):

@@ -96,10 +96,14 @@ class ivclabpose(object):
             print("Pose Detector : Close.")
         elif _cfg(self.pose_detector, 'NAME') == 'HRPose':
             from .hrnet import HRNetPose
+            # ivclabpose.py:107-111: gpu_args = every visible GPU.  One process drives ONE of them (`device`); several GPUs = several
+            # ranks of a torch.distributed job, and HRNetPose.predict shards each call's crops over them (see HRNetPose.__init__).
+            gpu_args = _Args(gpus=list(range(torch.cuda.device_count())), device=torch.device('cuda:%d' % device))
             self.pose_model = HRNetPose(_cfg(self.pose_detector, 'C'), _cfg(self.pose_detector, 'NUM_JOINTS'),
                                         _cfg(self.pose_detector, 'CHECKPOINT_FILE'),
                                         model_name=_cfg(self.pose_detector, 'MODEL_NAME'),
-                                        resolution=tuple(_cfg(self.pose_detector, 'RESOLUTION')), device=device)
+                                        resolution=tuple(_cfg(self.pose_detector, 'RESOLUTION')), hrpose_args=gpu_args,
+                                        device=device, max_dets=max_dets)
             print("Pose Detector : ", _cfg(self.pose_detector, 'NAME'))
         if self.person_matcher is None:
             print("Person Matcher : Close.")

@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import pam
-from pam.distributed import CropGather, ViewGather, crop_partition, view_partition
+from pam.distributed import CropGather, ViewGather, crop_partition, gather_crop_keypoints, view_partition
 
 
 def test_view_partition():
@@ -94,4 +94,28 @@ def test_crop_gather_world2_gloo():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_crop_worker, args=(2, _free_port(), 5, 4, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
+
+
+def _kp_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rng = np.random.default_rng(2)
+    ok = True
+    for n in (0, 1, 5, 20):                              # incl. a rank with nothing to decode
+        full = torch.tensor(rng.normal(size=(n, 17, 3)), dtype=torch.float32)
+        a, b = crop_partition(n, world)[rank]
+        out = gather_crop_keypoints(full[a:b].clone(), n, world, rank)
+        ok &= bool(torch.equal(out, full))
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_surface_keypoint_gather_world2_gloo():
+    """HRNetPose.predict's exchange under torch.distributed (the drop-in surface on several GPUs): every rank ends with all rows."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_kp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret[0] and ret[1]

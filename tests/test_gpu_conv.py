@@ -36,6 +36,9 @@ CASES = [
     (2, 12, 8, 384, 48, 1, 1, False, False),     # fuse 1x1
     (2, 16, 12, 48, 96, 3, 2, True, False),      # fuse stride-2 with accumulate
     (1, 7, 5, 96, 192, 3, 2, False, True),
+    (2, 20, 16, 48, 144, 3, 2, False, True),     # merged fuse-layer heads: 3 / 4 / 6 N tiles in one workgroup (tiles 5, 6, 7)
+    (2, 20, 16, 48, 192, 3, 2, False, True),
+    (2, 13, 11, 96, 288, 3, 2, False, True),
 ]
 
 
@@ -47,12 +50,15 @@ def eng():
 
 
 @pytest.mark.parametrize('case', CASES)
-@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv_vs_torch(eng, case, tile):
     from pam import _lib, hrnet_hip
     n, h, w, cin, cout, k, stride, use_res, relu = case
-    if tile in (1, 3) and (cout // (48 if cout % 48 == 0 else 64)) % 2:
-        pytest.skip('tile needs an even number of N tiles')
+    nb = cout // (48 if cout % 48 == 0 else 64)
+    if (tile in (1, 3) and nb % 2) or (tile in (5, 7) and nb % 3) or (tile == 6 and nb % 4):
+        pytest.skip('tile needs a matching number of N tiles')
+    if tile >= 5 and (k != 3 or stride != 2 or cout % 48):
+        pytest.skip('wide-N tiles are exercised on the strided fuse-layer shapes')
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(hash(case) % 1000)
     conv = nn.Conv2d(cin, cout, k, stride, k // 2, bias=True)

@@ -6,7 +6,7 @@ import torch, torch.nn as nn, torch.nn.functional as F
 import pam
 from pam import _lib, hrnet_hip
 
-ap = argparse.ArgumentParser(); ap.add_argument('--n', type=int, default=20); ap.add_argument('--tiles', default='-1'); ap.add_argument('--generic-all', action='store_true'); ap.add_argument('--no-miopen', action='store_true')
+ap = argparse.ArgumentParser(); ap.add_argument('--n', type=int, default=20); ap.add_argument('--tiles', default='-1'); ap.add_argument('--generic-all', action='store_true'); ap.add_argument('--no-miopen', action='store_true'); ap.add_argument('--fuse', action='store_true', help='the strided / 1x1 convolutions of the fuse layers (incl. merged ones)')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); e.lib = _lib.load(); e.device = dev
@@ -30,6 +30,10 @@ if args.generic_all:          # every layer shape of HRNet-W48 that runs on k_co
               (96, 72, 48, 48, 3, 2), (192, 144, 64, 64, 3, 2), (24, 18, 192, 384, 3, 2), (48, 36, 48, 192, 3, 2), (24, 18, 96, 384, 3, 2),
               (48, 36, 96, 96, 3, 2), (48, 36, 96, 48, 1, 1), (24, 18, 192, 96, 1, 1), (24, 18, 48, 384, 3, 2), (96, 72, 64, 64, 1, 1),
               (24, 18, 192, 48, 1, 1), (48, 36, 48, 48, 3, 2), (12, 9, 384, 192, 1, 1), (12, 9, 384, 96, 1, 1), (12, 9, 384, 48, 1, 1)]
+if args.fuse:
+    LAYERS = [(96, 72, 48, 144, 3, 2), (96, 72, 48, 192, 3, 2), (96, 72, 48, 96, 3, 2), (48, 36, 96, 192, 3, 2), (48, 36, 96, 288, 3, 2), (48, 36, 48, 192, 3, 2), (48, 36, 48, 48, 3, 2),
+              (24, 18, 192, 384, 3, 2), (24, 18, 96, 384, 3, 2), (24, 18, 48, 384, 3, 2), (48, 36, 96, 48, 1, 1), (24, 18, 192, 144, 1, 1), (12, 9, 384, 336, 1, 1),
+              (192, 144, 64, 64, 3, 2), (96, 72, 256, 96, 3, 2), (96, 72, 64, 256, 1, 1), (96, 72, 256, 64, 1, 1), (96, 72, 64, 64, 1, 1)]
 for (h, w, cin, cout, k, s) in LAYERS:
     conv = nn.Conv2d(cin, cout, k, s, k // 2, bias=True)
     op = hrnet_hip.PackedConv(conv, dev)
