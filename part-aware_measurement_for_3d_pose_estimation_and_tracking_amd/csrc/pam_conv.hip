@@ -179,6 +179,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx,
         for (int i = 0; i < 4; ++i) acc[i][j] = b4;
     }
 
+    // residual rows of this lane's 4 pixel tiles: issued BEFORE the K loop, so their latency runs under the operand loads and the
+    // MFMAs instead of in front of the stores (the 1x1 64 -> 256 + residual layers of layer1 are one K chunk long: nothing else hides it)
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.M * a.Cout * 2), 0x00020000);
+    uint32_t rres[4][2 * NTW];
+    if (a.res) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+            const size_t o = (size_t)m * a.Cout + cw0 + g * 4 * NTW;
+            c3_row_load<NTW>(rs_res, m < a.M ? (unsigned)(o * 2) : OOB_OFFSET, g, rres[i]);
+        }
+    }
+
     const int nchunks = a.Kpad / KC;
     load_chunk();
     store_chunk(0);
@@ -216,7 +229,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx,
 
     // epilogue straight from the accumulators: with the weights as the A operand the D tile has channels on its rows, so this
     // lane holds channels cw0 + 4*NTW*g + 4*j + r of pixel mw0 + i*16 + (lane & 15): 4*NTW contiguous channels, 16-byte accesses
-    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.M * a.Cout * 2), 0x00020000);
     const int mw0 = m0 + wm * 64;
     typedef __attribute__((ext_vector_type(2))) short s16x2;
 #pragma unroll
@@ -224,15 +236,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx,
         const int m = mw0 + i * 16 + (lane & 15);
         if (m < a.M) {
             const size_t o = (size_t)m * a.Cout + cw0 + g * 4 * NTW;
-            uint32_t rres[2 * NTW], ov[2 * NTW];
-            if (a.res) c3_row_load<NTW>(rs_res, (unsigned)(o * 2), g, rres);
+            uint32_t ov[2 * NTW];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 float rr[4] = {0.f, 0.f, 0.f, 0.f};
                 if (a.res) {
-                    rr[0] = __builtin_bit_cast(float, rres[2 * j] << 16); rr[1] = __builtin_bit_cast(float, rres[2 * j] & 0xffff0000u);
-                    rr[2] = __builtin_bit_cast(float, rres[2 * j + 1] << 16); rr[3] = __builtin_bit_cast(float, rres[2 * j + 1] & 0xffff0000u);
+                    rr[0] = __builtin_bit_cast(float, rres[i][2 * j] << 16); rr[1] = __builtin_bit_cast(float, rres[i][2 * j] & 0xffff0000u);
+                    rr[2] = __builtin_bit_cast(float, rres[i][2 * j + 1] << 16); rr[3] = __builtin_bit_cast(float, rres[i][2 * j + 1] & 0xffff0000u);
                 }
                 const bool act_on = cw0 + g * 4 * NTW + j * 4 >= a.relu_from;   // merged fuse-layer convs: only the upper channels
                 if constexpr (GEN) {

@@ -6,14 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.nn as nn
 import pam
 from pam import _lib, hrnet_hip
-dev = torch.device('cuda:0')
+dev = torch.device("cuda:0"); NB = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); e.lib = _lib.load(); e.device = dev
 buf = torch.zeros(4096 * 64, dtype=torch.int64, device=dev)
 e.lib.pam_conv_debug_stamps(C.c_void_p(buf.data_ptr()))
 for (h, w, cin, cout) in [(96, 72, 48, 48), (48, 36, 96, 96), (24, 18, 192, 192), (12, 9, 384, 384)]:
     conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=True); op = hrnet_hip.PackedConv(conv, dev)
-    x = torch.randn((20, cin, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
-    res = torch.randn((20, cout, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    x = torch.randn((NB, cin, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    res = torch.randn((NB, cout, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
     e.tile_cfg = -1
     for _ in range(3): e.conv(op, x, res=res, relu=True)
     buf.zero_(); e.tile_cfg = 164
