@@ -409,7 +409,9 @@ class HipHRNet(ConvEngine):
     lane_of = (0, 1, 2, 3)      # stream of branch b (0 = the caller's stream); issue order of the branches inside a module
     order = (0, 1, 2, 3)
     fuse_blocks = True          # BasicBlocks of the branches the fused kernel takes: one grouped launch per block level (caller's stream)
-    fuse_max_branches = 1       # ... at most this many leading branches (measured end to end at 20 crops: 1 -> 3.24 ms, 3 -> 3.46 ms, none -> 3.32 ms)
+    fuse_max_branches = None    # ... at most this many leading branches; None = by batch: 1 below 96 crops, 3 from there (measured end to end, one
+                                # box each: 20 crops none / 1 / 3 -> 3.08 / 3.14 / 3.46 ms; 60 crops 7.77 / 7.91 / 8.23 ms; 217 crops 29.0 / 28.2 / 27.1 ms;
+                                # fused blocks move 16 % less HBM traffic and take 32 launches fewer per forward)
     fuse_waves = 8              # workgroup shape of the fused kernel (8 waves, one workgroup per CU, measured faster than 2 x 4 waves)
     group_fuse = False          # True: fuse layers as one launch per LEVEL of convolutions over all branches + one launch for all sums
                                 # (99 launches per forward instead of 263, but the fuse convolutions no longer run beside the coarse
@@ -436,11 +438,13 @@ class HipHRNet(ConvEngine):
         # which leading branches go through the fused, grouped kernel (shape supported by pam_basic_block_rows)
         grouped = []
         if self.fuse_blocks and xs[0] is not None:
+            n0 = (xs[0][2] if isinstance(xs[0], tuple) else xs[0]).shape[0]
+            fmax = self.fuse_max_branches if self.fuse_max_branches is not None else (3 if n0 >= 96 else 1)
             for b in range(len(mod['branches'])):
                 shp = xs[b][2].shape if isinstance(xs[b], tuple) else xs[b].shape
                 cb = mod['branches'][b][0][0].cin
                 hb, wb = (shp[2], shp[3]) if not isinstance(xs[b], tuple) else ((shp[2] + 2 - 3) // xs[b][1].stride + 1, (shp[3] + 2 - 3) // xs[b][1].stride + 1)
-                if mod['fused'][b] is not None and len(grouped) == b and len(grouped) < min(self.fuse_max_branches, _lib.PAM_BLOCK_MAX_BRANCHES) and \
+                if mod['fused'][b] is not None and len(grouped) == b and len(grouped) < min(fmax, _lib.PAM_BLOCK_MAX_BRANCHES) and \
                         self.lib.pam_basic_block_rows(cb, hb, wb, 0) > 0:
                     grouped.append(b)
         if grouped:
