@@ -219,8 +219,7 @@ __global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const
     for (int j = 0; j < JN; ++j) acc[j] = bias ? bias[j] : 0.0f;
     if (ok) {
         const uint16_t* f = feat + ((size_t)crop * HW + lp) * C;
-        for (int c8 = 0; c8 < C; c8 += 8) {
-            const uint4 v = *(const uint4*)(f + c8);
+        auto fma8 = [&](const uint4 v, int c8) {
             const uint32_t d[4] = {v.x, v.y, v.z, v.w};
             float x[8];
 #pragma unroll
@@ -229,6 +228,15 @@ __global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const
             for (int j = 0; j < JN; ++j)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[j] = fmaf(x[k], ws[j * C + c8 + k], acc[j]);
+        };
+        if (C == 48) {                                   // HRNet-W48: all six 16-byte pieces of the pixel in flight at once (same FMA order)
+            uint4 v[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v[q] = *(const uint4*)(f + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) fma8(v[q], 8 * q);
+        } else {
+            for (int c8 = 0; c8 < C; c8 += 8) fma8(*(const uint4*)(f + c8), c8);
         }
         if (heat) {
             float* o = heat + ((size_t)crop * HW + lp) * JN;
@@ -236,8 +244,9 @@ __global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const
             for (int j = 0; j < JN; ++j) o[j] = acc[j];
         }
     }
-    // per-joint (max, first index) over the workgroup's 256 pixels: the values go through LDS pixel-major (pitch JN + 1 words: the
-    // column reads below are conflict-free), then 8 lanes per joint scan 32 pixels each in index order and fold by 3 shuffles
+    // per-joint (max, first index) over the workgroup's 256 pixels: the values go through LDS pixel-major (pitch JN + 1 words), then
+    // 8 lanes per joint scan 32 pixels each -- lane `part` takes pixels part, part + 8, ...: increasing index inside a lane, and the 8
+    // lanes of a joint read 8 consecutive rows (different banks; blocks of 32 rows would all fall on one) -- and fold by 3 shuffles
     float* vs = (float*)(red + (HEAD_T / 64) * JN);                   // [HEAD_T][JN + 1]
 #pragma unroll
     for (int j = 0; j < JN; ++j) vs[threadIdx.x * (JN + 1) + j] = ok ? acc[j] : -__builtin_huge_valf();
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const
         Best b; b.v = -__builtin_huge_valf(); b.i = 0x7fffffff;
 #pragma unroll 8
         for (int q = 0; q < HEAD_T / 8; ++q) {
-            const int px = part * (HEAD_T / 8) + q;
+            const int px = q * 8 + part;
             const float v = vs[px * (JN + 1) + j];
             if (v > b.v) { b.v = v; b.i = tile * HEAD_T + px; }            // strictly greater: the first maximum of the part
         }
@@ -266,9 +275,16 @@ __global__ __launch_bounds__(64) void k_argmax_finish(int tiles, const Best* __r
     const int crop = blockIdx.x, j = threadIdx.x;
     if (j >= J) return;
     Best b; b.v = -__builtin_huge_valf(); b.i = 0x7fffffff;
-    for (int t = 0; t < tiles; ++t) {
-        const Best c = cand[((size_t)crop * tiles + t) * J + j];
-        if (c.v > b.v) b = c;                                         // tiles are in index order: strictly greater keeps the first maximum
+    for (int t0 = 0; t0 < tiles; t0 += 8) {                          // 8 candidates in flight at a time (a serial chain of 27 loads took 11 us)
+        Best c[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int t = min(t0 + q, tiles - 1);
+            c[q] = cand[((size_t)crop * tiles + t) * J + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (t0 + q < tiles && c[q].v > b.v) b = c[q];            // tiles are in index order: strictly greater keeps the first maximum
     }
     double* row = det + ((size_t)view_of[crop] * max_dets + slot_of[crop]) * J * 3;
     write_keypoint(j, b, hm_h, hm_w, boxes + crop * 4, row, kp ? kp + (size_t)crop * J * 3 : nullptr);
