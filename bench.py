@@ -312,11 +312,22 @@ def main():
     # ---- secondary measurements on rank 0, after the timed region -------------------------------------------------------------------------
     if rank == 0:
         def ev_time(fn, iters=50):
+            """Seconds per call on the GPU: `iters` calls captured into one hipGraph and replayed between two HIP events, so that the
+            host's launch cost (tens of us per call from Python) is not what gets measured."""
             fn(); torch.cuda.synchronize()
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                fn()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(iters):
+                    fn()
+            g.replay(); torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            for _ in range(iters):
-                fn()
+            g.replay()
             b.record(); torch.cuda.synchronize()
             return a.elapsed_time(b) / iters * 1e-3
         e = inp['per_frame'][W + K - 1]
