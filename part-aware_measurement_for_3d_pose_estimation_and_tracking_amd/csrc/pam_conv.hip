@@ -95,8 +95,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bx,
     constexpr int APT = (BM * 8 + T - 1) / T;          // A pieces (16 B) per thread per chunk (the last pass is partial when T does not divide BM * 8)
     constexpr int BPT = (BN * 8 + T - 1) / T;          // B pieces per thread per chunk
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* As = smem;                                   // [2][BM][ROWB]
-    char* Bs = smem + 2 * BM * ROWB;                   // [2][BN][ROWB]
+    // two chunk buffers each -- or one when the whole K is a single chunk (1x1 layers with 64 input channels: half the LDS, twice
+    // the workgroups per CU for layers that are one load -> multiply -> store chain per workgroup)
+    const int nbuf = a.Kpad > KC ? 2 : 1;
+    char* As = smem;                                   // [nbuf][BM][ROWB]
+    char* Bs = smem + nbuf * BM * ROWB;                // [nbuf][BN][ROWB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = bx * BM, n0 = by * BN;
@@ -293,13 +296,13 @@ static int launch_conv(hipStream_t s, const ConvArgs& a) {
     constexpr int BM_ = 64 * WM, BN_ = 16 * NTW * WN;
     if (a.relu > 1) {                                   // Darknet activation codes: the general-epilogue instantiation
         dim3 grid((a.M + BM_ - 1) / BM_, a.Cout / BN_);
-        const size_t lds = 2 * (size_t)(BM_ + BN_) * ROWB;
+        const size_t lds = (a.Kpad > KC ? 2 : 1) * (size_t)(BM_ + BN_) * ROWB;
         hipLaunchKernelGGL((k_conv_igemm<NTW, WM, WN, true>), grid, dim3(64 * WM * WN), lds, s, a);
         return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
     }
     constexpr int BM = 64 * WM, BN = 16 * NTW * WN;
     dim3 grid((a.M + BM - 1) / BM, a.Cout / BN);
-    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
+    const size_t lds = (a.Kpad > KC ? 2 : 1) * (size_t)(BM + BN) * ROWB;
     hipLaunchKernelGGL((k_conv_igemm<NTW, WM, WN, false>), grid, dim3(64 * WM * WN), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
@@ -661,6 +664,9 @@ static int launch_c3(hipStream_t s, const C3Args& a, int cfg) {
         case 42: return npatch <= 160 ? launch_c3_one<CIN, NTW, 4, 2, 160>(s, a) : launch_c3_one<CIN, NTW, 4, 2, 288>(s, a);
         case 43: return npatch <= 160 ? launch_c3_one<CIN, NTW, 4, 3, 160>(s, a) : launch_c3_one<CIN, NTW, 4, 3, 352>(s, a);
         case 44: return npatch <= 288 ? launch_c3_one<CIN, NTW, 4, 4, 288>(s, a) : launch_c3_one<CIN, NTW, 4, 4, 416>(s, a);
+        case 54:                                         // 5 M tiles per wave (320 slots): taller tiles -> a layer of <= 256 workgroups, each alone on its CU
+            if constexpr (CIN == 96 || CIN == 192) return launch_c3_one<CIN, NTW, 5, 4, 416>(s, a);
+            else return PAM_E_ARG;
     }
     return PAM_E_ARG;
 }
@@ -828,7 +834,7 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         c.tiles_y = (H + c.TH - 1) / c.TH;
         hipStream_t s = (hipStream_t)stream;
         // rows too wide for the patch-in-LDS kernel (e.g. the detector's 208-wide layers): the generic kernel takes them
-        const int npatch = (c.TH + 2) * (W + 2), pmax = (cfg == 44) ? 416 : (cfg == 43 ? 352 : 288);
+        const int npatch = (c.TH + 2) * (W + 2), pmax = (cfg == 44 || cfg == 54) ? 416 : (cfg == 43 ? 352 : 288);
         const bool fits = npatch <= pmax && c3_lds_bytes(Cin, ntw, npatch) <= 150 * 1024 && Cout % (16 * ntw) == 0 &&
                           (relu <= 1 || c3_general_act(Cin));
         if (!fits && tile_cfg >= 100) return PAM_E_ARG;
@@ -941,7 +947,7 @@ extern "C" int pam_conv2d_group_nhwc_bf16(void* stream, int n, const PamConvDesc
     }
     for (int k = n; k < PAM_CONV_GROUP_MAX; ++k) { g.c[k] = g.c[0]; g.first[k] = blocks; }
     g.first[PAM_CONV_GROUP_MAX] = blocks;
-    const size_t lds = 2 * (size_t)(64 + 48) * ROWB;
+    const size_t lds = 2 * (size_t)(64 + 48) * ROWB;          // members may differ in K: always both buffers
     hipLaunchKernelGGL(k_conv_igemm_group, dim3(blocks), dim3(64), lds, (hipStream_t)stream, g);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

@@ -13,12 +13,20 @@ e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); e.lib = _lib.load(); e.devic
 
 
 def timeit(fn, iters=30):
+    """us per call on the GPU: `iters` calls captured into one hipGraph and replayed between two events (a Python launch costs ~20 us:
+    eager timing cannot resolve these kernels)."""
     for _ in range(3): fn()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side): fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    keep = []
+    with torch.cuda.graph(g):
+        for _ in range(iters): keep.append(fn())
+    g.replay(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(True), torch.cuda.Event(True)
-    a.record()
-    for _ in range(iters): fn()
-    b.record(); torch.cuda.synchronize()
+    a.record(); g.replay(); b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
 
 
