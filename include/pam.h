@@ -194,6 +194,11 @@ int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void* w_packed, 
                             int stride, int pad, int relu, int tile_cfg, int in_cstride, int relu_from);
 /* output channels per workgroup slab (BN) that k_conv3x3 uses for a layer shape; weight images must be packed with it */
 int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
+/* 0: w_img of this layer is the classic per-chunk image described above; BN > 0: the layer runs on the streamed kernel k_conv3x3s
+ * (Cin 192 / 384 at tile_cfg == -1) with slabs of BN output channels and w_img must be [Cout/BN][Cin/32][9 taps][BN rows][4][8]
+ * bf16: chunk c, tap t, row r (same row -> channel rule as above) holds input channels 32*c + 8*g .. + 8 of that tap in its 16-byte
+ * piece g ^ ((r >> 1) & 2).  tile_cfg == -2 forces the classic kernel (and the classic image) for such a layer. */
+int pam_conv3x3_layout(int H, int W, int Cin, int Cout);
 /* diagnostic builds only: device buffer (64 x uint64 per workgroup) for k_conv3x3's s_memtime stamps, used when tile_cfg = 100 + 64 */
 int pam_conv_debug_stamps(void* dev_buf);
 int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, const void* const* terms,

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 #include "../../include/pam.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;     // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
@@ -61,6 +62,12 @@ __device__ __forceinline__ void c3_row_load(__amdgpu_buffer_rsrc_t rs, unsigned 
     } else if constexpr (NTW == 4) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0), w = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16, 0, 0);
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; d[4] = w[0]; d[5] = w[1]; d[6] = w[2]; d[7] = w[3];
+    } else if constexpr (NTW == 6) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o + 16 * k, 0, 0);
+            d[4 * k] = v[0]; d[4 * k + 1] = v[1]; d[4 * k + 2] = v[2]; d[4 * k + 3] = v[3];
+        }
     } else {
         static_assert(NTW == 3, "slab width");
         const bool odd = g & 1;
@@ -78,6 +85,9 @@ __device__ __forceinline__ void c3_row_store(uint16_t* p, int g, const uint32_t*
         *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]};
     } else if constexpr (NTW == 4) {
         *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]}; *(u32x4*)(p + 8) = (u32x4){d[4], d[5], d[6], d[7]};
+    } else if constexpr (NTW == 6) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *(u32x4*)(p + 8 * k) = (u32x4){d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]};
     } else {
         const bool odd = g & 1;
         *(u32x4*)(p + (odd ? 4 : 0)) = odd ? (u32x4){d[2], d[3], d[4], d[5]} : (u32x4){d[0], d[1], d[2], d[3]};
@@ -704,6 +714,264 @@ extern "C" int pam_conv3x3_slab(int H, int W, int Cin, int Cout) {
 }
 
 // ====================================================================================================================
+// k_conv3x3s: the same convolution (Cin = 192 / 384, activation codes 0 / 1) with SPECIALISED waves.  In k_conv3x3 at 20 crops a
+// workgroup is alone on its CU, so every wave pays for its own operand traffic in its own instruction stream: the burst of
+// buffer_loads for the next chunk holds the MFMA stream for ~1.6 k cycles per chunk, the register -> LDS pass for another ~1 k, against
+// 1.7-2.3 k cycles of MFMAs (tools/stamp_conv.py knock-outs).  Here waves 4-7 only move bytes -- LDS-DMA (global_load_lds_dwordx4: no
+// registers, no ds_write pass) of 32-channel chunks into a ring of NBUF chunk buffers, NBUF - 1 chunks ahead -- and waves 0-3 only
+// read fragments and multiply (one per SIMD, MT x NTW accumulator tiles each as before).  One raw s_barrier per chunk: the loaders
+// arrive once chunk k has landed (counted vmcnt, younger chunks stay in flight), the multipliers once they are done with chunk
+// k - 1, whose buffer the loaders then refill.
+//   chunk buffer = [PMAX patch slots][64 B] + [9 taps][BN rows][64 B], both dense (a DMA piece is 1 KiB = 16 rows, lane-linear) with
+//   the 16-B piece g of row r stored at position g ^ ((r >> 1) & 2): conflict-free ds_read_b128 for a 16-row window at ANY row offset
+//   (tools/lds_sim.py).  Patch rows outside the image are fetched from a page of zeros; the weight images are host-packed in exactly
+//   this layout (pam_conv3x3_layout() == 1).  The residual is added to the bias before the K loop (its loads run beside the first
+//   chunk's DMA), so the epilogue is convert + ReLU + store.
+// ====================================================================================================================
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+__device__ __attribute__((aligned(64))) const uint32_t g_c3_zero[16 + 16 * 16] = {0};   // 64 B + the largest chunk offset (Cin = 512)
+
+// scheduling pattern of one k-step: the next step's NR LDS reads alternate with the first NR of this step's NM MFMAs, the other MFMAs
+// follow (slack for the last read's latency); the builtin takes literal counts
+template <int NM, int NR, int... R>
+__device__ __forceinline__ void c3s_spread(std::integer_sequence<int, R...>) {
+    (((void)R, __builtin_amdgcn_sched_group_barrier(0x008, 1, 0), __builtin_amdgcn_sched_group_barrier(0x100, 1, 0)), ...);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+}
+
+template <int CIN, int NTW, int MT, int PMAX, int NBUF>
+__global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
+    constexpr int BN = 16 * NTW, NCHUNK = CIN / 32;
+    constexpr int PIMG = PMAX * 64, WIMG = 9 * BN * 64, BUF = PIMG + WIMG;
+    constexpr int PPW = PMAX / 64, WPIECES = WIMG / 1024, WPW = (WPIECES + 3) / 4, NPER = PPW + WPW;   // DMA pieces per loader wave per chunk
+    static_assert(PMAX % 64 == 0 && BUF % 512 == 0 && WIMG % 1024 == 0 && NPER * (NBUF - 1) <= 60 && NBUF >= 2 && NBUF <= 4, "ring shape");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = a.tiles_y * a.N;
+    const int bx = [&] {                                // XCD-aware tile order (see k_conv3x3)
+        const int v = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, loc = v >> 3;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }();
+    const int n = bx / a.tiles_y, ty0 = (bx - n * a.tiles_y) * a.TH;
+    const int PW = a.W + 2, npatch = (a.TH + 2) * PW;
+    const int nslots = min(a.TH, a.H - ty0) * PW;
+    const int n0 = blockIdx.y * BN;
+
+    if (wave >= 4) {
+        // ---- loader waves ---------------------------------------------------------------------------------------------------
+        const int lw = wave - 4;
+        const char* psrc[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int s = (lw + 4 * i) * 16 + (lane >> 2);                               // slot this lane fills in piece lw + 4 i
+            const int gsrc = (lane & 3) ^ ((s >> 1) & 2);
+            const int py = fdiv_small(s, a.inv_pw), px = s - py * PW;
+            const int iy = ty0 - 1 + py, ix = px - 1;
+            const bool ok = s < npatch && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            psrc[i] = ok ? (const char*)a.in + (((size_t)n * a.H + iy) * a.W + ix) * (CIN * 2) + gsrc * 16 : (const char*)g_c3_zero + (lane & 3) * 16;
+        }
+        const char* wsrc = (const char*)a.wimg + (size_t)blockIdx.y * NCHUNK * WIMG + lane * 16;
+        auto issue = [&](int c) {
+            char* dst = smem + (size_t)((unsigned)c % (unsigned)NBUF) * BUF;
+#pragma unroll
+            for (int i = 0; i < (PPW > WPW ? PPW : WPW); ++i) {
+                if (i < WPW) {
+                    const int j = min(lw + 4 * i, WPIECES - 1);                          // a wave short of a piece re-sends the last one
+                    __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + (size_t)c * WIMG + j * 1024), (lds_void*)(dst + PIMG + j * 1024), 16, 0, 0);
+                }
+                if (i < PPW)
+                    __builtin_amdgcn_global_load_lds((glb_void*)(psrc[i] + c * 64), (lds_void*)(dst + (lw + 4 * i) * 1024), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < NBUF - 1; ++c)
+            if (c < NCHUNK) issue(c);
+        for (int k = 0; k < NCHUNK; ++k) {
+            const int fly = min(NCHUNK - 1 - k, NBUF - 2);                               // younger chunks that may stay in flight
+            if (fly <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPER) : "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (k + NBUF - 1 < NCHUNK) issue(k + NBUF - 1);
+        }
+        return;
+    }
+
+    // ---- multiplier waves ---------------------------------------------------------------------------------------------------
+    C3_STAMP(0);
+    f32x4 acc[MT][NTW];
+    {
+        f32x4 bias4[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (a.res) {
+            const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
+            uint32_t rres[MT][2 * NTW];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int p = wave * 16 * MT + i * 16 + (lane & 15);
+                const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
+                const bool ok = p < nslots && px < a.W;
+                const unsigned o = ok ? (unsigned)(((((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4 * NTW) * 2) : OOB_OFFSET;
+                c3_row_load<NTW>(rs_res, o, g, rres[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    acc[i][j][0] = bias4[j][0] + __builtin_bit_cast(float, rres[i][2 * j] << 16);
+                    acc[i][j][1] = bias4[j][1] + __builtin_bit_cast(float, rres[i][2 * j] & 0xffff0000u);
+                    acc[i][j][2] = bias4[j][2] + __builtin_bit_cast(float, rres[i][2 * j + 1] << 16);
+                    acc[i][j][3] = bias4[j][3] + __builtin_bit_cast(float, rres[i][2 * j + 1] & 0xffff0000u);
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[i][j] = bias4[j];
+        }
+    }
+    // LDS byte offsets (inside a chunk buffer) of this lane's patch fragment for M tile i and tap t, swizzle included
+    unsigned aoff[MT][9];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int s = wave * 16 * MT + i * 16 + (lane & 15) + (t / 3) * PW + (t % 3);
+            aoff[i][t] = (unsigned)(s * 64 + ((g ^ ((s >> 1) & 2)) << 4));
+        }
+    const unsigned woff = (unsigned)(PIMG + (lane & 15) * 64 + ((g ^ ((lane >> 1) & 2)) << 4));   // row j*16 + (lane & 15): bit 2 of the row = bit 2 of the lane
+
+    // One software pipeline over all NCHUNK * 9 k-steps: the fragments of step s + 1 are read while the MFMAs of step s issue, and a
+    // chunk boundary (drain this wave's LDS reads, barrier, first reads of the next chunk) sits between the last tap's reads and its
+    // MFMAs, so the barrier and the first read latency of a chunk hide under 12 MFMAs.  Fragment slots alternate with (k + t) & 1.
+    bf16x8 af[2][MT], bfr[2][NTW];
+    auto ldfrag = [&](int k, int t, bf16x8* af_, bf16x8* bf_) {
+        const char* buf = smem + (size_t)((unsigned)k % (unsigned)NBUF) * BUF;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bf_[j] = *(const bf16x8*)(buf + woff + (t * BN + j * 16) * 64);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af_[i] = *(const bf16x8*)(buf + aoff[i][t]);
+    };
+    auto chunk = [&](int k, auto PARC) {
+        constexpr int PAR = decltype(PARC)::value;
+        C3_STAMP(3 + 3 * (k & 15));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = (t + PAR) & 1, nxt = cur ^ 1;
+            if (t + 1 < 9) ldfrag(k, t + 1, af[nxt], bfr[nxt]);
+            else if (k + 1 < NCHUNK) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0): this wave is done reading chunk k
+                asm volatile("s_barrier" ::: "memory");                                   // chunk k + 1 has landed; chunk k's buffer is free
+                ldfrag(k + 1, 0, af[nxt], bfr[nxt]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[cur][j]),
+                                                                       __builtin_bit_cast(bf16x8_t, af[cur][i]), acc[i][j], 0, 0, 0);
+            // issue order inside the step: the next step's MT + NTW fragment reads spread between this step's MFMAs (a burst of reads
+            // ahead of the MFMAs holds the wave's issue slot ~100 cycles per step with the matrix pipe idle)
+            c3s_spread<MT * NTW, MT + NTW>(std::make_integer_sequence<int, MT + NTW>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        C3_STAMP(4 + 3 * (k & 15));
+    };
+    asm volatile("s_barrier" ::: "memory");                                              // chunk 0 has landed (and is visible)
+    ldfrag(0, 0, af[0], bfr[0]);
+    for (int k = 0; k < NCHUNK; k += 2) {
+        chunk(k, std::integral_constant<int, 0>{});
+        if (k + 1 < NCHUNK) chunk(k + 1, std::integral_constant<int, 1>{});
+    }
+    C3_STAMP(60);
+
+    // ---- epilogue straight from the accumulators (row permutation of the slab as in k_conv3x3: 4*NTW contiguous channels per lane)
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int p = wave * 16 * MT + i * 16 + (lane & 15);
+        const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
+        if (p < nslots && px < a.W) {
+            uint32_t ov[2 * NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                ov[2 * j] = pack_bf16x2(acc[i][j][0], acc[i][j][1]); ov[2 * j + 1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                if (a.relu) {
+                    ov[2 * j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j]), (s16x2){0, 0}));
+                    ov[2 * j + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j + 1]), (s16x2){0, 0}));
+                }
+            }
+            c3_row_store<NTW>(a.out + (((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4 * NTW, g, ov);
+        }
+    }
+    C3_STAMP(61);
+}
+
+// Which layers the streamed kernel takes, and its tile.  The register tile of a multiplier wave sets the LDS traffic per MFMA
+// ((MT + NTW) fragment reads per MT * NTW MFMAs): with 32-channel slabs the four multipliers' reads take 75-85 % of the LDS cycles of
+// their MFMAs and a chunk runs at half the matrix rate; slabs of 64 channels halve that and give the same latency
+// from HALF the workgroups (120-160 at 20 crops), which leaves the other CUs to the other branches' kernels.  One workgroup per CU
+// (LDS ring): the tile is the tallest whole-row tile that fits (a divisor of H when that costs < 15 %).
+// Cin 96 stays on k_conv3x3: its streamed form (96-channel slabs, 160 workgroups) is as fast alone (12.9 vs 13.0 us) but 3-5 % slower
+// end to end -- a 150 KB workgroup shuts the other branches out of its CU, and the 48 x 36 layers have enough tiles to fill the chip.
+static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax, int& ntw) {
+    if (Cin != 192 && Cin != 384) return false;
+#ifdef PAM_DIAG
+    static const int mask = getenv("PAM_C3S_MASK") ? atoi(getenv("PAM_C3S_MASK")) : 6;       // tuning hook: 2 = Cin 192, 4 = 384
+    if (!(mask & (Cin == 192 ? 2 : 4))) return false;
+#endif
+    const int PW = W + 2, smax = 320, pcap = 384;
+    TH = smax / PW;
+    while (TH > 1 && (TH + 2) * PW > pcap) --TH;
+    if (TH < 1) return false;
+    if (TH > H) TH = H;
+    for (int t = TH; t >= 1 && t * 100 >= TH * 85; --t) if (H % t == 0) { TH = t; break; }
+    const int slots = TH * PW, npatch = (TH + 2) * PW;
+    if (slots > smax || npatch > pcap) return false;
+    mt = slots <= 192 ? 3 : (slots <= 256 ? 4 : 5);
+    pmax = npatch <= 192 ? 192 : (npatch <= 320 ? 320 : 384);
+    const int bn = 64;
+    if (Cout % bn != 0) return false;
+    ntw = bn / 16;
+    return (mt == 3 && pmax == 192) || (mt == 4 && pmax == 320) || (mt == 5 && pmax == 384);      // instantiated shapes
+}
+extern "C" int pam_conv3x3_layout(int H, int W, int Cin, int Cout) {
+    int th, mt, pmax, ntw;
+    return c3s_pick(H, W, Cin, Cout, th, mt, pmax, ntw) ? 16 * ntw : 0;
+}
+template <int CIN, int NTW, int MT, int PMAX, int NBUF>
+static int launch_c3s_one(hipStream_t s, const C3Args& a) {
+    constexpr size_t lds = (size_t)NBUF * (PMAX * 64 + 9 * 16 * NTW * 64);
+    static_assert(lds <= 160 * 1024, "LDS");
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>), dim3(a.tiles_y * a.N, a.Cout / (16 * NTW)), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt) {
+#ifdef PAM_DIAG
+    static const int nbuf = getenv("PAM_C3S_NBUF") ? atoi(getenv("PAM_C3S_NBUF")) : 0;       // tuning hook
+    if (Cin == 384 && ntw == 4 && mt == 3 && nbuf == 2) return launch_c3s_one<384, 4, 3, 192, 2>(s, a);
+#endif
+    switch (Cin * 100 + ntw * 10 + mt) {
+        case 19243: return launch_c3s_one<192, 4, 3, 192, 3>(s, a);
+        case 19244: return launch_c3s_one<192, 4, 4, 320, 2>(s, a);
+        case 19245: return launch_c3s_one<192, 4, 5, 384, 2>(s, a);
+        case 38443: return launch_c3s_one<384, 4, 3, 192, 3>(s, a);
+        case 38444: return launch_c3s_one<384, 4, 4, 320, 2>(s, a);
+        case 38445: return launch_c3s_one<384, 4, 5, 384, 2>(s, a);
+    }
+    return PAM_E_ARG;
+}
+
+// ====================================================================================================================
 // k_conv_stem: the first convolution of both networks' stems -- 3x3 / stride 1 or 2 / pad 1 from the 8-channel (RGB + zeros)
 // input to 32 or 64 channels.  K per tap ROW is 3 taps x 8 channels = 24 <= 32, so one v_mfma_f32_16x16x32_bf16 covers a whole tap row:
 // lane (pixel l & 15, k-group g = l >> 4) supplies as its B fragment the 16-byte input pixel (2y + ky - 1, 2x + g - 1)
@@ -813,6 +1081,23 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         else hipLaunchKernelGGL((k_conv_stem<1, 2>), grid, blk, 0, s, t);
         return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
     }
+    if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && tile_cfg == -1) {
+        // streamed kernel (specialised loader / multiplier waves): w_img then has the layout pam_conv3x3_layout() > 0 announces.
+        // Any other tile_cfg (-2 = classic kernel, >= 100 = tuning hooks) takes the classic kernel and the classic images.
+        C3Args c;
+        int mt = 0, pmax = 0, ntw = 0;
+        if (c3s_pick(H, W, Cin, Cout, c.TH, mt, pmax, ntw)) {
+            if (relu > 1) return PAM_E_ARG;
+            c.in = a.in; c.wimg = (const uint16_t*)w_img; c.bias = bias; c.res = a.res; c.out = a.out;
+            c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.relu = relu; c.inv_pw = 1.0f / (float)(W + 2);
+            c.tiles_y = (H + c.TH - 1) / c.TH;
+#ifdef PAM_DIAG
+            c.dbg = g_c3_stamps ? 64 : 0; c.stamps = g_c3_stamps;
+#endif
+            return launch_c3s((hipStream_t)stream, c, Cin, ntw, mt);
+        }
+    }
+    if (tile_cfg == -2) tile_cfg = -1;
     if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&
         (Cin == 48 || Cin == 64 || Cin == 96 || Cin == 192 || Cin == 384 || Cin == 128 || Cin == 256 || Cin == 512)) {
         const int ntw = pam_conv3x3_slab(H, W, Cin, Cout) / 16;

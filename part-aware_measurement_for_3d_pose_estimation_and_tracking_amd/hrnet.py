@@ -191,7 +191,7 @@ def algorithmic_work(n_crops, resolution=(384, 288)):
 
     class _MetaLib(object):
         def __getattr__(self, name):
-            if name in ('pam_basic_block_rows', 'pam_conv3x3_slab'):       # pure host-side shape queries: the executor's plan depends on them
+            if name in ('pam_basic_block_rows', 'pam_conv3x3_slab', 'pam_conv3x3_layout'):       # pure host-side shape queries: the executor's plan depends on them
                 return getattr(_real.load(), name)
             return lambda *a, **k: 0
     eng = HipHRNet.__new__(HipHRNet)

@@ -69,29 +69,41 @@ class PackedConv(object):
             m.bias.copy_(torch.cat([(c.bias.detach().float() if c.bias is not None else torch.zeros(c.out_channels)) for c in convs]))
         return PackedConv(m, device)
 
-    def image(self, h, w):
-        """Weight image [cout/BN][cin/CK][BN][pitch/2] bf16 (row = 9 taps x CK channels + pad) for this layer at input h x w."""
+    def image(self, h, w, classic=False):
+        """Weight image of this layer at input h x w for the rows-in-LDS kernels (layouts: include/pam.h): the classic per-chunk image
+        [cout/BN][cin/CK][BN][pitch/2] (row = 9 taps x CK channels + pad), or -- where pam_conv3x3_layout() says so and the caller does
+        not force the classic kernel -- the streamed kernel's [cout/BN][cin/32][9][BN][4][8] with swizzled 16-byte pieces."""
         if self._stem is not None:
             return self._stem
         if self._w_ohwi is None:
             return None
-        bn = _lib.load().pam_conv3x3_slab(int(h), int(w), self.cin, self.cout)
+        lib = _lib.load()
+        bn_s = 0 if classic else lib.pam_conv3x3_layout(int(h), int(w), self.cin, self.cout)     # > 0: streamed kernel, with this slab width
+        streamed = bn_s > 0
+        bn = bn_s if streamed else lib.pam_conv3x3_slab(int(h), int(w), self.cin, self.cout)
         if self.cout % bn != 0:
             return None                                  # no whole number of slabs: the generic kernel takes this layer
-        img = self._images.get(bn)
+        img = self._images.get((bn, streamed))
         if img is None:
             cin, cout = self.cin, self.cout
-            ck = 48 if cin == 48 else (64 if cin >= 192 else 32)
-            pitch = {48: 864, 32: 608, 64: 1184}[ck] // 2
-            w5 = self._w_ohwi.reshape(cout // bn, bn, 9, cin // ck, ck)                  # [slab][co][tap][chunk][c]
             # row j*16 + q of a slab holds channel 4*ntw*(q >> 2) + 4*j + (q & 3): with the weights as the MFMA A operand a
             # lane's accumulators are then 4*ntw contiguous output channels (16-byte epilogue accesses, see k_conv3x3)
             ntw = bn // 16
-            w5 = w5[:, [4 * ntw * (q >> 2) + 4 * j + (q & 3) for j in range(ntw) for q in range(16)]]
-            t = torch.zeros((cout // bn, cin // ck, bn, pitch), dtype=torch.float32)
-            t[:, :, :, :9 * ck] = w5.permute(0, 3, 1, 2, 4).reshape(cout // bn, cin // ck, bn, 9 * ck)
+            perm = [4 * ntw * (q >> 2) + 4 * j + (q & 3) for j in range(ntw) for q in range(16)]
+            if streamed:
+                w5 = self._w_ohwi.reshape(cout // bn, bn, 9, cin // 32, 32)[:, perm]       # [slab][row][tap][chunk][c]
+                t = w5.permute(0, 3, 2, 1, 4).reshape(cout // bn, cin // 32, 9, bn, 4, 8)  # [slab][chunk][tap][row][piece][8]
+                rows = torch.arange(bn)
+                src = torch.arange(4)[None, :] ^ ((rows >> 1) & 2)[:, None]                # physical piece p of row r holds logical piece p ^ ((r >> 1) & 2)
+                t = torch.gather(t, 4, src[None, None, None, :, :, None].expand(t.shape))
+            else:
+                ck = 48 if cin == 48 else (64 if cin >= 192 else 32)
+                pitch = {48: 864, 32: 608, 64: 1184}[ck] // 2
+                w5 = self._w_ohwi.reshape(cout // bn, bn, 9, cin // ck, ck)[:, perm]       # [slab][co][tap][chunk][c]
+                t = torch.zeros((cout // bn, cin // ck, bn, pitch), dtype=torch.float32)
+                t[:, :, :, :9 * ck] = w5.permute(0, 3, 1, 2, 4).reshape(cout // bn, cin // ck, bn, 9 * ck)
             img = t.to(torch.bfloat16).to(self._device).contiguous()
-            self._images[bn] = img
+            self._images[(bn, streamed)] = img
         return img
 
 
@@ -158,7 +170,7 @@ class ConvEngine(object):
         if x.device.type == 'meta':
             return y
         act = self.ACT[relu] | (4 if (res_after_act and res is not None) else 0)
-        wimg = op.image(h, w) if (in_cs == cin and relu_from == 0) else None
+        wimg = op.image(h, w, classic=(self.tile_cfg != -1)) if (in_cs == cin and relu_from == 0) else None
         st = torch.cuda.current_stream(x.device).cuda_stream
         launch = lambda: self.lib.pam_conv2d_nhwc_bf16_ex(
             C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
@@ -584,28 +596,41 @@ class HipHRNet(ConvEngine):
         self._keep = []
         return self._features(x8)
 
-    def _features(self, x8):
-        x = self.conv(self.conv1, x8, relu=True)
-        x = self.conv(self.conv2, x, relu=True)
-        for b in self.layer1:
-            r = x if b['down'] is None else self.conv(b['down'], x)
-            y = self.conv(b['c1'], x, relu=True)
-            y = self.conv(b['c2'], y, relu=True)
-            x = self.conv(b['c3'], y, res=r, relu=True)
-        self._barrier()                                               # branch streams must see layer1's output
-        xs = [('lazy', self.t1[0], x), ('lazy', self.t1[1], x)]
-        for m in self.stage2:
-            xs = self._hr_module(m, xs)
-        self._barrier()                                               # the new branch's stream reads the last sum of stage 2
-        xs = xs + [('lazy', self.t2, xs[-1])]
-        for m in self.stage3:
-            xs = self._hr_module(m, xs)
-        self._barrier()
-        xs = xs + [('lazy', self.t3, xs[-1])]
-        for m in self.stage4:
-            xs = self._hr_module(m, xs)
+    stop_after = None           # diagnostics (tools/stage_times.py): 'stem' | 'layer1' | 'stage2' | 'stage3' -> the forward ends there
+
+    def _end(self, xs):
         if self.multi_stream:                                         # final join only (no re-fork: capture must end with no forked stream)
             cur = torch.cuda.current_stream(self.device)
             for st in self.side:
                 cur.wait_stream(st)
         return xs[0]
+
+    def _features(self, x8):
+        x = self.conv(self.conv1, x8, relu=True)
+        x = self.conv(self.conv2, x, relu=True)
+        if self.stop_after == 'stem':
+            return x
+        for b in self.layer1:
+            r = x if b['down'] is None else self.conv(b['down'], x)
+            y = self.conv(b['c1'], x, relu=True)
+            y = self.conv(b['c2'], y, relu=True)
+            x = self.conv(b['c3'], y, res=r, relu=True)
+        if self.stop_after == 'layer1':
+            return x
+        self._barrier()                                               # branch streams must see layer1's output
+        xs = [('lazy', self.t1[0], x), ('lazy', self.t1[1], x)]
+        for m in self.stage2:
+            xs = self._hr_module(m, xs)
+        if self.stop_after == 'stage2':
+            return self._end(xs)
+        self._barrier()                                               # the new branch's stream reads the last sum of stage 2
+        xs = xs + [('lazy', self.t2, xs[-1])]
+        for m in self.stage3:
+            xs = self._hr_module(m, xs)
+        if self.stop_after == 'stage3':
+            return self._end(xs)
+        self._barrier()
+        xs = xs + [('lazy', self.t3, xs[-1])]
+        for m in self.stage4:
+            xs = self._hr_module(m, xs)
+        return self._end(xs)

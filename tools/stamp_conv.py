@@ -7,6 +7,7 @@ import numpy as np, torch, torch.nn as nn
 import pam
 from pam import _lib, hrnet_hip
 dev = torch.device("cuda:0"); NB = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+EXTRA = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # extra knock-out bits: 1 = no global loads, 32 = no LDS store pass, 2 = no MFMA loop
 e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); e.lib = _lib.load(); e.device = dev
 buf = torch.zeros(4096 * 64, dtype=torch.int64, device=dev)
 e.lib.pam_conv_debug_stamps(C.c_void_p(buf.data_ptr()))
@@ -16,7 +17,7 @@ for (h, w, cin, cout) in [(96, 72, 48, 48), (48, 36, 96, 96), (24, 18, 192, 192)
     res = torch.randn((NB, cout, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
     e.tile_cfg = -1
     for _ in range(3): e.conv(op, x, res=res, relu=True)
-    buf.zero_(); e.tile_cfg = 164
+    buf.zero_(); e.tile_cfg = 164 + EXTRA
     e.conv(op, x, res=res, relu=True); torch.cuda.synchronize()
     st = buf.cpu().numpy().reshape(-1, 64)
     st = st[st[:, 0] > 0]
