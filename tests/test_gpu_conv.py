@@ -39,6 +39,14 @@ CASES = [
     (2, 20, 16, 48, 144, 3, 2, False, True),     # merged fuse-layer heads: 3 / 4 / 6 N tiles in one workgroup (tiles 5, 6, 7)
     (2, 20, 16, 48, 192, 3, 2, False, True),
     (2, 13, 11, 96, 288, 3, 2, False, True),
+    # streamed kernel k_conv3x3s (Cin 192 / 384): its three tile shapes, full-size layers, ragged last tile, Cout != Cin
+    (20, 24, 18, 192, 192, 3, 1, True, True),    # 4 M tiles per wave, 320-slot patch
+    (20, 12, 9, 384, 384, 3, 1, True, True),     # 3 M tiles, 192-slot patch
+    (3, 16, 12, 192, 192, 3, 1, False, True),
+    (2, 40, 6, 192, 64, 3, 1, True, False),      # 5 M tiles, 384-slot patch
+    (2, 25, 18, 384, 128, 3, 1, True, True),     # ragged last row tile
+    (1, 8, 6, 384, 384, 3, 1, False, False),
+    (5, 3, 3, 192, 192, 3, 1, True, True),       # image smaller than one M tile
 ]
 
 
@@ -83,6 +91,34 @@ def test_conv_vs_torch(eng, case, tile):
     err = (y.float() - ref).abs()
     tol = 2.0 ** -7 * ref.abs() + 2e-2          # one bf16 rounding of the result + fp32 accumulation-order slack
     assert bool((err <= tol).all()), (case, tile, err.max().item())
+
+
+@pytest.mark.parametrize('shape', [(20, 24, 18, 192, 192), (20, 12, 9, 384, 384), (2, 25, 18, 384, 128), (2, 40, 6, 192, 64)])
+def test_streamed_kernel_is_the_default_and_matches_the_classic_one(eng, shape):
+    """pam_conv3x3_layout() announces the streamed kernel for these layers; tile_cfg = -2 forces k_conv3x3 on the classic weight image.
+    Same products, different summation order (the streamed kernel starts from bias + residual): equal up to a bf16 rounding here and there."""
+    from pam import _lib, hrnet_hip
+    n, h, w, cin, cout = shape
+    lib = _lib.load()
+    assert lib.pam_conv3x3_layout(h, w, cin, cout) == 64
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (cin * 9)) ** 0.5)
+        conv.bias.copy_(torch.randn(cout, generator=g))
+    op = hrnet_hip.PackedConv(conv, dev)
+    x = torch.randn((n, cin, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    res = torch.randn((n, cout, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
+    e.lib = lib; e.device = dev
+    e.tile_cfg = -1; y = e.conv(op, x, res=res, relu=True)
+    e.tile_cfg = -2; u = e.conv(op, x, res=res, relu=True)
+    torch.cuda.synchronize()
+    assert op._images[(64, True)].shape == (cout // 64, cin // 32, 9, 64, 4, 8)
+    d = (y.float() - u.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(u.float().abs().max()) + 1e-6
+    assert float((d > 0).float().mean()) < 0.02
 
 
 def test_upsample_add_vs_torch():
