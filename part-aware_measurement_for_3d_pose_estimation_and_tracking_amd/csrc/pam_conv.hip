@@ -972,6 +972,224 @@ static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt) 
 }
 
 // ====================================================================================================================
+// k_conv_gs: the implicit GEMM (1x1 and strided 3x3 layers) with the wave roles of k_conv3x3s.  Waves 4-7 gather the im2col tile
+// -- 256 output pixels x 64 K values per chunk, every 16-byte piece fetched from its own address (or from a page of zeros: padding,
+// K tail, rows past M) -- and the slab's weight rows straight from the packed [Cout][Kpad] matrix, by LDS-DMA into a ring of NBUF chunk
+// buffers; waves 0-3 read fragments and multiply (64 pixels x 16*NTW channels each).  Rows are dense 128 bytes with the 16-byte
+// piece q of row r at position q ^ ((r >> 1) & 7): conflict-free ds_read_b128 for a 16-row window x 4 k-groups, and a lane's
+// fragment addresses are constants + immediates.  One s_barrier per chunk (loaders: chunk k has landed; multipliers: chunk k - 1 is
+// consumed), residual folded into the bias before the K loop, epilogue = convert + ReLU (channels >= relu_from) + 16-byte stores.
+// ====================================================================================================================
+template <int NTW, int NBUF>
+__global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
+    constexpr int BM = 256, BN = 16 * NTW, AIMG = BM * 128, BIMG = BN * 128, BUF = AIMG + BIMG;
+    constexpr int APW = AIMG / 1024 / 4, BPIECES = BIMG / 1024, BPW = (BPIECES + 3) / 4, NPER = APW + BPW;
+    static_assert(NPER * (NBUF - 1) <= 60 && NBUF >= 2 && NBUF <= 4, "ring shape");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = a.Kpad >> 6;
+    // PERSISTENT: workgroup b walks tiles b, b + gridDim.x, ... (tile = (256-pixel block, slab), slabs of one block adjacent so that
+    // they fetch the same pixels at about the same time); the chunk ring runs on across tile boundaries, so a tile's loads overlap
+    // the previous tile's multiplies and epilogue -- with one workgroup per CU nothing else would
+    const int nslab = a.Cout / BN, ntile = ((a.M + BM - 1) / BM) * nslab;
+    const int mine = (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = mine * nchunks;
+
+    if (wave >= 4) {
+        // ---- loader waves ---------------------------------------------------------------------------------------------------
+        const int lw = wave - 4;
+        // A piece lw + 4 i covers rows 8 (lw + 4 i) .. + 7; this lane fills row 8 (lw + 4 i) + (lane >> 3), position lane & 7, i.e. the
+        // logical piece q = (lane & 7) ^ ((row >> 1) & 7) -- the same q for all of its rows
+        const int q = (lane & 7) ^ ((4 * lw + (lane >> 4)) & 7);
+        int base[APW]; unsigned mask[APW];
+        const char* bsrc[BPW]; int bdst[BPW];
+        const int hw = a.Ho * a.Wo;
+        const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
+        auto setup_tile = [&](int t) __attribute__((always_inline)) {
+            const int T = (int)blockIdx.x + t * (int)gridDim.x, m0 = (T / nslab) * BM, n0 = (T % nslab) * BN;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const int m = m0 + (lw + 4 * i) * 8 + (lane >> 3);
+                base[i] = 0; mask[i] = 0;
+                if (m < a.M) {
+                    // m -> (n, oy, ox) by float reciprocals + one integer correction (exact below 2^24; integer division is ~40 instructions)
+                    int n = (int)((float)m * inv_hw), r = m - n * hw;
+                    if (r < 0) { --n; r += hw; } else if (r >= hw) { ++n; r -= hw; }
+                    int oy = (int)((float)r * inv_wo), ox = r - oy * a.Wo;
+                    if (ox < 0) { --oy; ox += a.Wo; } else if (ox >= a.Wo) { ++oy; ox -= a.Wo; }
+                    const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                    base[i] = (int)((((long)n * a.H + iy0) * a.W + ix0) * a.in_cs * 2);    // may be "before" the tensor; used with valid taps only
+                    unsigned cols = 0, mk = 0;                                            // valid taps = valid rows x valid columns
+                    for (int kx = 0; kx < a.KW; ++kx) if ((unsigned)(ix0 + kx) < (unsigned)a.W) cols |= 1u << kx;
+                    for (int ky = 0; ky < a.KH; ++ky) if ((unsigned)(iy0 + ky) < (unsigned)a.H) mk |= cols << (ky * a.KW);
+                    mask[i] = mk;
+                }
+            }
+            // B piece j covers slab rows 8 j .. + 7; LDS row jt*16 + qq holds output channel 4*NTW*(qq >> 2) + 4*jt + (qq & 3) of the slab
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const int j = min(lw + 4 * i, BPIECES - 1);                              // a wave short of a piece re-sends the last one
+                const int row = j * 8 + (lane >> 3), qq = row & 15, jt = row >> 4;
+                const int ch = n0 + 4 * NTW * (qq >> 2) + 4 * jt + (qq & 3);
+                const int qb = (lane & 7) ^ ((row >> 1) & 7);
+                bsrc[i] = (const char*)a.w + ((size_t)ch * a.Kpad + qb * 8) * 2;
+                bdst[i] = AIMG + j * 1024;
+            }
+        };
+        const float inv_cin = 1.0f / (float)a.Cin;
+        int issued = 0, it = 0, ic = 0;                                                  // issue pointer: chunk ic of my tile it
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            char* dst = smem + (size_t)((unsigned)issued % (unsigned)NBUF) * BUF;
+            const int k0 = ic * 64 + q * 8;                                              // this lane's 8 K values: one tap, 8 channels
+            const int tap = (int)(((float)k0 + 0.5f) * inv_cin), cc = k0 - tap * a.Cin;
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            const int delta = ((ky * a.W + kx) * a.in_cs + cc) * 2;
+            const unsigned bit = k0 < a.Ktot ? 1u << tap : 0u;
+#pragma unroll
+            for (int i = 0; i < BPW; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void*)(bsrc[i] + ic * 128), (lds_void*)(dst + bdst[i]), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const char* src = (mask[i] & bit) ? (const char*)a.in + (long)base[i] + delta : (const char*)g_c3_zero;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + (lw + 4 * i) * 1024), 16, 0, 0);
+            }
+            ++issued;
+            if (++ic == nchunks) { ic = 0; if (++it < mine) setup_tile(it); }
+        };
+        setup_tile(0);
+#pragma unroll
+        for (int c = 0; c < NBUF - 1; ++c)
+            if (issued < total) issue_next();
+        for (int k = 0; k < total; ++k) {
+            const int fly = min(total - 1 - k, NBUF - 2);                                // younger chunks that may stay in flight
+            if (fly <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPER) : "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (issued < total) issue_next();
+        }
+        return;
+    }
+
+    // ---- multiplier waves ---------------------------------------------------------------------------------------------------
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.M * a.Cout * 2), 0x00020000);
+    uint32_t rres[4][2 * NTW];
+    auto res_load = [&](int t) {                                                         // residual rows of my tile t -> registers (in flight)
+        const int T = (int)blockIdx.x + t * (int)gridDim.x, mw0 = (T / nslab) * BM + wave * 64, n0 = (T % nslab) * BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mw0 + i * 16 + (lane & 15);
+            c3_row_load<NTW>(rs_res, m < a.M ? (unsigned)(((size_t)m * a.Cout + n0 + g * 4 * NTW) * 2) : OOB_OFFSET, g, rres[i]);
+        }
+    };
+    if (a.res) res_load(0);
+    // fragment addresses: row (lane & 15) of a 16-row window, k-group g of k-step ks -> piece (4 ks + g) ^ ((lane & 15) >> 1)
+    const unsigned sw = (unsigned)((g ^ ((lane & 15) >> 1)) << 4);                       // ks = 0; ks = 1 is sw ^ 64
+    const unsigned aoff0 = (unsigned)((wave * 64 + (lane & 15)) * 128) + sw;
+    const unsigned boff0 = (unsigned)(AIMG + (lane & 15) * 128) + sw;
+    f32x4 acc[4][NTW];
+    bf16x8 af[2][4], bfr[2][NTW];
+    auto ldfrag = [&](int G, int ks, bf16x8* af_, bf16x8* bf_) {
+        const char* buf = smem + (size_t)((unsigned)G % (unsigned)NBUF) * BUF;
+        const unsigned x = ks ? 64u : 0u;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bf_[j] = *(const bf16x8*)(buf + ((boff0 ^ x) + j * 16 * 128));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af_[i] = *(const bf16x8*)(buf + ((aoff0 ^ x) + i * 16 * 128));
+    };
+    auto mfmas = [&](const bf16x8* af_, const bf16x8* bf_) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf_[j]), __builtin_bit_cast(bf16x8_t, af_[i]), acc[i][j], 0, 0, 0);
+    };
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    asm volatile("s_barrier" ::: "memory");                                              // my first chunk has landed (and is visible)
+    int G = 0;
+    for (int t = 0; t < mine; ++t) {
+        const int T = (int)blockIdx.x + t * (int)gridDim.x, mw0 = (T / nslab) * BM + wave * 64, n0 = (T % nslab) * BN;
+        {   // accumulators start from bias (+ residual, requested a tile ago)
+            f32x4 bias4[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    acc[i][j] = bias4[j];
+                    if (a.res) {
+                        acc[i][j][0] += __builtin_bit_cast(float, rres[i][2 * j] << 16);
+                        acc[i][j][1] += __builtin_bit_cast(float, rres[i][2 * j] & 0xffff0000u);
+                        acc[i][j][2] += __builtin_bit_cast(float, rres[i][2 * j + 1] << 16);
+                        acc[i][j][3] += __builtin_bit_cast(float, rres[i][2 * j + 1] & 0xffff0000u);
+                    }
+                }
+        }
+        ldfrag(G, 0, af[0], bfr[0]);
+        for (int c = 0; c < nchunks; ++c, ++G) {
+            ldfrag(G, 1, af[1], bfr[1]);
+            mfmas(af[0], bfr[0]);
+            c3s_spread<4 * NTW, 4 + NTW>(std::make_integer_sequence<int, 4 + NTW>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (G + 1 < total) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0): this wave is done reading chunk G
+                asm volatile("s_barrier" ::: "memory");                                   // chunk G + 1 has landed; chunk G's buffer is free
+                if (c + 1 < nchunks) ldfrag(G + 1, 0, af[0], bfr[0]);
+                else if (a.res) res_load(t + 1);                                         // next tile's residual: lands under the epilogue
+            }
+            mfmas(af[1], bfr[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // epilogue: this lane holds channels n0 + 4*NTW*g + 4*j + r of pixel mw0 + i*16 + (lane & 15)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = mw0 + i * 16 + (lane & 15);
+            if (m < a.M) {
+                uint32_t ov[2 * NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    ov[2 * j] = pack_bf16x2(acc[i][j][0], acc[i][j][1]); ov[2 * j + 1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                    if (a.relu && n0 + g * 4 * NTW + j * 4 >= a.relu_from) {
+                        ov[2 * j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j]), (s16x2){0, 0}));
+                        ov[2 * j + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j + 1]), (s16x2){0, 0}));
+                    }
+                }
+                c3_row_store<NTW>(a.out + (size_t)m * a.Cout + n0 + g * 4 * NTW, g, ov);
+            }
+        }
+    }
+}
+// Layers the streamed implicit GEMM takes by default (measured against k_conv_igemm per HRNet layer shape at 20 crops, tools/bench_conv.py
+// --fuse --tiles=-2,8): at least two K chunks (a one-chunk tile is a load -> multiply -> store chain with nothing to overlap), and a
+// tile count that suits one persistent workgroup per CU: a single round, or well-filled rounds, or a single slab (no other workgroup
+// shares the gathered pixels, where k_conv_igemm's two-slab tiles would win).  270 tiles = 256 + 14 is the case to avoid: two rounds for 5 %.
+static bool conv_gs_auto(const ConvArgs& a) {
+    const int bn = a.Cout % 48 == 0 ? 48 : 64, nslab = a.Cout / bn, tiles = ((a.M + 255) / 256) * nslab;
+    if (a.Kpad < 128) return false;
+#ifdef PAM_DIAG
+    static const int mode = getenv("PAM_GS") ? atoi(getenv("PAM_GS")) : 1;                // tuning hook: 0 = never, 2 = always
+    if (mode != 1) return mode == 2;
+#endif
+    const int rounds = (tiles + 255) / 256;
+    return nslab == 1 || tiles <= 256 || tiles * 100 >= rounds * 256 * 78;
+}
+template <int NTW>
+static int launch_conv_gs(hipStream_t s, const ConvArgs& a) {
+    constexpr int NBUF = 3;
+    constexpr size_t lds = (size_t)NBUF * (256 + 16 * NTW) * 128;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)k_conv_gs<NTW, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
+        attr = true;
+    }
+    const int ntile = ((a.M + 255) / 256) * (a.Cout / (16 * NTW));
+    hipLaunchKernelGGL((k_conv_gs<NTW, NBUF>), dim3(ntile < 256 ? ntile : 256), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+// ====================================================================================================================
 // k_conv_stem: the first convolution of both networks' stems -- 3x3 / stride 1 or 2 / pad 1 from the 8-channel (RGB + zeros)
 // input to 32 or 64 channels.  K per tap ROW is 3 taps x 8 channels = 24 <= 32, so one v_mfma_f32_16x16x32_bf16 covers a whole tap row:
 // lane (pixel l & 15, k-group g = l >> 4) supplies as its B fragment the 16-byte input pixel (2y + ky - 1, 2x + g - 1)
@@ -1097,7 +1315,8 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
             return launch_c3s((hipStream_t)stream, c, Cin, ntw, mt);
         }
     }
-    if (tile_cfg == -2) tile_cfg = -1;
+    const bool classic = tile_cfg == -2;                 // -2: the classic kernels (k_conv3x3 / k_conv_igemm), automatic tiles
+    if (classic) tile_cfg = -1;
     if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (tile_cfg < 0 || tile_cfg >= 100) &&
         (Cin == 48 || Cin == 64 || Cin == 96 || Cin == 192 || Cin == 384 || Cin == 128 || Cin == 256 || Cin == 512)) {
         const int ntw = pam_conv3x3_slab(H, W, Cin, Cout) / 16;
@@ -1148,6 +1367,11 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         }
     }
     if (tile_cfg >= 100) tile_cfg = -1;
+    // streamed implicit GEMM (k_conv_gs): codes 0 / 1, taps in a 32-bit mask, whole 16-byte pieces per tap (Cin % 8 == 0)
+    const bool gs_ok = relu <= 1 && KH * KW <= 9 && Cin % 8 == 0 && (size_t)N * H * W * in_cstride * 2 < (1u << 31);
+    if (tile_cfg == 8 && !gs_ok) return PAM_E_ARG;
+    if (gs_ok && (tile_cfg == 8 || (tile_cfg == -1 && !classic && conv_gs_auto(a))))
+        return (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
     return (Cout % 48 == 0) ? dispatch_conv<3>((hipStream_t)stream, a, tile_cfg) : dispatch_conv<4>((hipStream_t)stream, a, tile_cfg);
 }
 
