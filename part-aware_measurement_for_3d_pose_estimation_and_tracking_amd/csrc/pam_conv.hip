@@ -995,6 +995,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
     const int nslab = a.Cout / BN, ntile = ((a.M + BM - 1) / BM) * nslab;
     const int mine = (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total = mine * nchunks;
+    // XCD-aware order: workgroups b, b + 8, ... share an XCD and its L2 (gridDim.x is a multiple of 8 whenever a workgroup walks more
+    // than one tile), so every XCD gets a contiguous run of the (block, slab) list: the slabs of one pixel block then gather the same
+    // input pixels through ONE L2 instead of pulling them over the fabric once per XCD
+    auto tile_of = [&](int t) {
+        const int v = (int)blockIdx.x + t * (int)gridDim.x, qn = ntile >> 3, rn = ntile & 7, xcd = v & 7, loc = v >> 3;
+        return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + loc;
+    };
 
     if (wave >= 4) {
         // ---- loader waves ---------------------------------------------------------------------------------------------------
@@ -1007,7 +1014,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
         const int hw = a.Ho * a.Wo;
         const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
         auto setup_tile = [&](int t) __attribute__((always_inline)) {
-            const int T = (int)blockIdx.x + t * (int)gridDim.x, m0 = (T / nslab) * BM, n0 = (T % nslab) * BN;
+            const int T = tile_of(t), m0 = (T / nslab) * BM, n0 = (T % nslab) * BN;
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
                 const int m = m0 + (lw + 4 * i) * 8 + (lane >> 3);
@@ -1076,7 +1083,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.M * a.Cout * 2), 0x00020000);
     uint32_t rres[4][2 * NTW];
     auto res_load = [&](int t) {                                                         // residual rows of my tile t -> registers (in flight)
-        const int T = (int)blockIdx.x + t * (int)gridDim.x, mw0 = (T / nslab) * BM + wave * 64, n0 = (T % nslab) * BN;
+        const int T = tile_of(t), mw0 = (T / nslab) * BM + wave * 64, n0 = (T % nslab) * BN;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = mw0 + i * 16 + (lane & 15);
@@ -1109,7 +1116,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
     asm volatile("s_barrier" ::: "memory");                                              // my first chunk has landed (and is visible)
     int G = 0;
     for (int t = 0; t < mine; ++t) {
-        const int T = (int)blockIdx.x + t * (int)gridDim.x, mw0 = (T / nslab) * BM + wave * 64, n0 = (T % nslab) * BN;
+        const int T = tile_of(t), mw0 = (T / nslab) * BM + wave * 64, n0 = (T % nslab) * BN;
         {   // accumulators start from bias (+ residual, requested a tile ago)
             f32x4 bias4[NTW];
 #pragma unroll
