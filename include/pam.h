@@ -200,6 +200,13 @@ int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
  * bf16: chunk c, tap t, row r (same row -> channel rule as above) holds input channels 32*c + 8*g .. + 8 of that tap in its 16-byte
  * piece g ^ ((r >> 1) & 2).  tile_cfg == -2 forces the classic kernel (and the classic image) for such a layer. */
 int pam_conv3x3_layout(int H, int W, int Cin, int Cout);
+/* which kernel the calling thread's last pam_conv2d_nhwc_bf16[_ex] call launched (labels for per-kernel profiles) */
+#define PAM_CONV_KERNEL_IGEMM 0   /* k_conv_igemm */
+#define PAM_CONV_KERNEL_3X3   1   /* k_conv3x3   */
+#define PAM_CONV_KERNEL_3X3S  2   /* k_conv3x3s  */
+#define PAM_CONV_KERNEL_GS    3   /* k_conv_gs   */
+#define PAM_CONV_KERNEL_STEM  4   /* k_conv_stem */
+int pam_conv_last_kernel(void);
 /* diagnostic builds only: device buffer (64 x uint64 per workgroup) for k_conv3x3's s_memtime stamps, used when tile_cfg = 100 + 64 */
 int pam_conv_debug_stamps(void* dev_buf);
 int pam_upsample_add_nhwc_bf16(void* stream, const void* base, int n_terms, const void* const* terms,

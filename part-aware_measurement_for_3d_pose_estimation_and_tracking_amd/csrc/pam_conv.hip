@@ -1275,6 +1275,10 @@ extern "C" int pam_conv2d_nhwc_bf16(void* stream, const void* in, const void* w_
     return pam_conv2d_nhwc_bf16_ex(stream, in, w_packed, w_img, bias, residual, out, N, H, W, Cin, Cout, KH, KW, stride, pad, relu,
                                    tile_cfg, Cin, 0);
 }
+// which kernel the last pam_conv2d_nhwc_bf16[_ex] call of this thread launched (profiling labels: bench.py's per-family roofline)
+static thread_local int g_last_conv_kernel = 0;
+extern "C" int pam_conv_last_kernel(void) { return g_last_conv_kernel; }
+#define CONV_KIND(k) (g_last_conv_kernel = (k))
 extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void* w_packed, const void* w_img, const float* bias,
                                        const void* residual, void* out, int N, int H, int W, int Cin, int Cout,
                                        int KH, int KW, int stride, int pad, int relu, int tile_cfg, int in_cstride, int relu_from) {
@@ -1300,6 +1304,7 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         t.N = N; t.H = H; t.W = W; t.Ho = a.Ho; t.Wo = a.Wo; t.relu = relu;
         const dim3 grid((N * a.Ho + 3) / 4), blk(256);
         hipStream_t s = (hipStream_t)stream;
+        CONV_KIND(PAM_CONV_KERNEL_STEM);
         if (stride == 2 && Cout == 64) hipLaunchKernelGGL((k_conv_stem<2, 4>), grid, blk, 0, s, t);
         else if (stride == 2) hipLaunchKernelGGL((k_conv_stem<2, 2>), grid, blk, 0, s, t);
         else if (Cout == 64) hipLaunchKernelGGL((k_conv_stem<1, 4>), grid, blk, 0, s, t);
@@ -1319,6 +1324,7 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
 #ifdef PAM_DIAG
             c.dbg = g_c3_stamps ? 64 : 0; c.stamps = g_c3_stamps;
 #endif
+            CONV_KIND(PAM_CONV_KERNEL_3X3S);
             return launch_c3s((hipStream_t)stream, c, Cin, ntw, mt);
         }
     }
@@ -1349,6 +1355,7 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         const bool fits = npatch <= pmax && c3_lds_bytes(Cin, ntw, npatch) <= 150 * 1024 && Cout % (16 * ntw) == 0 &&
                           (relu <= 1 || c3_general_act(Cin));
         if (!fits && tile_cfg >= 100) return PAM_E_ARG;
+        if (fits) CONV_KIND(PAM_CONV_KERNEL_3X3);
         if (fits) switch (Cin * 10 + ntw) {
             case 483: return launch_c3<48, 3>(s, c, cfg);
             case 643: return launch_c3<64, 3>(s, c, cfg);
@@ -1378,7 +1385,8 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     const bool gs_ok = relu <= 1 && KH * KW <= 9 && Cin % 8 == 0 && (size_t)N * H * W * in_cstride * 2 < (1u << 31);
     if (tile_cfg == 8 && !gs_ok) return PAM_E_ARG;
     if (gs_ok && (tile_cfg == 8 || (tile_cfg == -1 && !classic && conv_gs_auto(a))))
-        return (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
+        return CONV_KIND(PAM_CONV_KERNEL_GS), (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
+    CONV_KIND(PAM_CONV_KERNEL_IGEMM);
     return (Cout % 48 == 0) ? dispatch_conv<3>((hipStream_t)stream, a, tile_cfg) : dispatch_conv<4>((hipStream_t)stream, a, tile_cfg);
 }
 

@@ -181,12 +181,13 @@ class ConvEngine(object):
         if rc != 0:
             raise _lib.PamError('pam_conv2d_nhwc_bf16 failed (%d) for %s' % (rc, (x.shape, op.cout, op.kh, op.stride)))
         if self.prof is not None:
-            if op._stem is not None:
+            kind = self.lib.pam_conv_last_kernel()
+            if kind == 4:
                 fam = 'k_conv_stem %d->%d' % (3, op.cout)
-            elif wimg is not None:
-                fam = 'k_conv3x3 C=%d %dx%d' % (op.cin, h, w)
+            elif kind in (1, 2):
+                fam = '%s C=%d %dx%d' % ('k_conv3x3s' if kind == 2 else 'k_conv3x3', op.cin, h, w)
             else:
-                fam = 'k_conv_igemm %dx%d stride %d' % (op.kh, op.kw, op.stride)
+                fam = '%s %dx%d stride %d' % ('k_conv_gs' if kind == 3 else 'k_conv_igemm', op.kh, op.kw, op.stride)
             self._prof_add(x, fam, (n, h, w, op.cin, op.cout, res is not None, in_cs, relu_from),
                            2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin + (y.numel() if res is not None else 0)) + 4 * op.cout,
                            2 * y.numel() * op.kh * op.kw * op.cin, launch)
