@@ -925,19 +925,23 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
     if (!(mask & (Cin == 192 ? 2 : 4))) return false;
 #endif
     const int PW = W + 2, smax = 320, pcap = 384;
-    TH = smax / PW;
-    while (TH > 1 && (TH + 2) * PW > pcap) --TH;
+    // rows per tile: the height that costs the fewest M tiles over the image (a tile always multiplies whole 64-slot wave shares, 3 to
+    // 5 of them, and a ragged last tile multiplies as much as a full one); ties go to the taller tile = fewer workgroups
+    TH = 0; mt = 0; pmax = 0;
+    long best = 0;
+    for (int t = (H < smax / PW ? H : smax / PW); t >= 1; --t) {
+        const int sl = t * PW, np = (t + 2) * PW;
+        if (np > pcap) continue;
+        // the instantiated (M tiles per wave, patch slots) shapes: (3, 192), (4, 320), (5, 384) -- the smallest that holds the tile
+        const int m = (sl <= 192 && np <= 192) ? 3 : ((sl <= 256 && np <= 320) ? 4 : 5);
+        const long cost = (long)((H + t - 1) / t) * m;
+        if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : 384); }
+    }
     if (TH < 1) return false;
-    if (TH > H) TH = H;
-    for (int t = TH; t >= 1 && t * 100 >= TH * 85; --t) if (H % t == 0) { TH = t; break; }
-    const int slots = TH * PW, npatch = (TH + 2) * PW;
-    if (slots > smax || npatch > pcap) return false;
-    mt = slots <= 192 ? 3 : (slots <= 256 ? 4 : 5);
-    pmax = npatch <= 192 ? 192 : (npatch <= 320 ? 320 : 384);
     const int bn = 64;
     if (Cout % bn != 0) return false;
     ntw = bn / 16;
-    return (mt == 3 && pmax == 192) || (mt == 4 && pmax == 320) || (mt == 5 && pmax == 384);      // instantiated shapes
+    return true;
 }
 extern "C" int pam_conv3x3_layout(int H, int W, int Cin, int Cout) {
     int th, mt, pmax, ntw;

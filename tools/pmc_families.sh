@@ -16,9 +16,12 @@ FAMS=(
  "k_bblock_C192_24x18|--shape 24,18,192,192,3,1 --block 1"
  "k_conv3x3_C48_96x72|--shape 96,72,48,48,3,1"
  "k_conv3x3_C96_48x36|--shape 48,36,96,96,3,1"
- "k_conv3x3_C192_24x18|--shape 24,18,192,192,3,1"
- "k_conv3x3_C384_12x9|--shape 12,9,384,384,3,1"
+ "k_conv3x3s_C192_24x18|--shape 24,18,192,192,3,1"
+ "k_conv3x3s_C384_12x9|--shape 12,9,384,384,3,1"
  "k_conv_igemm_3x3s2_48to96_96x72|--shape 96,72,48,96,3,2 --res 0"
+ "k_conv_gs_3x3s2_96to288_48x36|--shape 48,36,96,288,3,2 --res 0"
+ "k_conv_gs_3x3s2_64to64_192x144|--shape 192,144,64,64,3,2 --res 0"
+ "k_conv_gs_1x1_256to64_96x72|--shape 96,72,256,64,1,1 --res 0"
  "k_conv_igemm_1x1_96to48_48x36|--shape 48,36,96,48,1,1 --res 0"
  "k_conv_igemm_1x1_64to256_96x72|--shape 96,72,64,256,1,1"
 )
