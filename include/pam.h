@@ -163,6 +163,14 @@ long long pam_head_decode_scratch_bytes(int n, int hm_h, int hm_w);
 int pam_head_decode(void* stream, int n, int hm_h, int hm_w, const void* feat_bf16, int C, const float* w, const float* bias, int J,
                     float* dev_heatmaps_or_null, const int32_t* dev_view_of, const int32_t* dev_slot_of, const float* dev_boxes,
                     int max_dets, double* dev_det, float* dev_kp_xyc, void* dev_scratch);
+/* the same pass with a SOFT arg-max decode (optional mode; the hard arg-max above is the parity mode): per joint the keypoint is the
+ * softmax(beta * heat-map)-weighted mean (column, row) over the crop's heat-map -- sub-pixel -- mapped through the box like the hard
+ * one; the confidence stays the heat-map maximum.  Per-tile partials (max, sum exp, weighted sums) merged streaming-softmax style;
+ * dev_scratch: pam_head_decode_soft_scratch_bytes(n, hm_h, hm_w) bytes.  beta > 0. */
+long long pam_head_decode_soft_scratch_bytes(int n, int hm_h, int hm_w);
+int pam_head_decode_soft(void* stream, int n, int hm_h, int hm_w, const void* feat_bf16, int C, const float* w, const float* bias, int J,
+                         float beta, float* dev_heatmaps_or_null, const int32_t* dev_view_of, const int32_t* dev_slot_of,
+                         const float* dev_boxes, int max_dets, double* dev_det, float* dev_kp_xyc, void* dev_scratch);
 int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames /*dev array of n_views frame ptrs*/,
                          int frame_h, int frame_w, const int32_t* dev_view_of, const float* dev_boxes,
                          int out_h, int out_w, int out_c /*3, or 8 = RGB + 5 zero channels*/, void* dev_out_bf16);

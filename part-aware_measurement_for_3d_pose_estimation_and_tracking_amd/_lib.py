@@ -105,6 +105,8 @@ _SIGS = {
     'pam_upsample_add_group_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_head_decode_scratch_bytes': (C.c_longlong, [_I, _I, _I]),
     'pam_head_decode': (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    'pam_head_decode_soft_scratch_bytes': (C.c_longlong, [_I, _I, _I]),
+    'pam_head_decode_soft': (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, C.c_float, _P, _P, _P, _P, _I, _P, _P, _P]),
     'pam_head_heatmaps': (_I, [_P, _I, _P, _I, _P, _P, _I, _P]),
     'pam_resize_frames': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'pam_upsample_concat_nhwc_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),

@@ -64,13 +64,26 @@ __device__ __forceinline__ Best wave_argmax(Best x) {
     }
     return x;
 }
-__device__ __forceinline__ void write_keypoint(int j, Best b, int hm_h, int hm_w, const float* box, double* det_row, float* kp_row) {
-    const int py = b.i / hm_w, pxx = b.i % hm_w;
+__device__ __forceinline__ void write_keypoint_at(int j, double py, double pxx, float score, int hm_h, int hm_w, const float* box,
+                                                  double* det_row, float* kp_row) {
     // upstream SimpleHRNet.predict: pt / (res // 4) * box extent + box origin, stored float32
-    const float y = (float)((double)py / (double)hm_h * (double)box[3] + (double)box[1]);
-    const float x = (float)((double)pxx / (double)hm_w * (double)box[2] + (double)box[0]);
-    det_row[j * 3 + 0] = (double)y; det_row[j * 3 + 1] = (double)x; det_row[j * 3 + 2] = (double)b.v;
-    if (kp_row) { kp_row[j * 3 + 0] = x; kp_row[j * 3 + 1] = y; kp_row[j * 3 + 2] = b.v; }
+    const float y = (float)(py / (double)hm_h * (double)box[3] + (double)box[1]);
+    const float x = (float)(pxx / (double)hm_w * (double)box[2] + (double)box[0]);
+    det_row[j * 3 + 0] = (double)y; det_row[j * 3 + 1] = (double)x; det_row[j * 3 + 2] = (double)score;
+    if (kp_row) { kp_row[j * 3 + 0] = x; kp_row[j * 3 + 1] = y; kp_row[j * 3 + 2] = score; }
+}
+__device__ __forceinline__ void write_keypoint(int j, Best b, int hm_h, int hm_w, const float* box, double* det_row, float* kp_row) {
+    write_keypoint_at(j, (double)(b.i / hm_w), (double)(b.i % hm_w), b.v, hm_h, hm_w, box, det_row, kp_row);
+}
+// soft-arg-max partial of one joint over a set of pixels: m = max, s = sum exp(beta (v - m)), sx / sy = the same sum weighted with the
+// pixel's column / row.  Two partials merge by rescaling both to the larger maximum (the usual streaming softmax).
+struct Soft { float m, s, sx, sy; };
+__device__ __forceinline__ Soft soft_merge(Soft a, Soft b, float beta) {
+    if (b.s == 0.0f) return a;
+    if (a.s == 0.0f) return b;
+    const float m = fmaxf(a.m, b.m), fa = __expf(beta * (a.m - m)), fb = __expf(beta * (b.m - m));
+    Soft r; r.m = m; r.s = a.s * fa + b.s * fb; r.sx = a.sx * fa + b.sx * fb; r.sy = a.sy * fa + b.sy * fb;
+    return r;
 }
 
 // NHWC heat-maps (n, H, W, 17) float32: one workgroup per person.  Pixel tiles of 256 x 17 floats are staged through LDS
@@ -203,10 +216,11 @@ extern "C" int pam_head_heatmaps(void* stream, int n_pix, const void* feat_bf16,
 // chain as k_head, so the values are bit-identical), the workgroup reduces (max, first index) per joint -- wave shuffles, then
 // LDS staging, 8 lanes per joint -- and writes J candidates to cand[crop][tile][J].  k_argmax_finish: one wave per crop folds the
 // tiles in order (strictly greater replaces: the lowest flat index wins ties, np.argmax's rule) and writes the keypoint rows.
-template <int JN>
+template <int JN, bool SOFT>
 __global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const uint16_t* __restrict__ feat, int C,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        float* __restrict__ heat /* optional */, Best* __restrict__ cand) {
+                                                        float* __restrict__ heat /* optional */, Best* __restrict__ cand,
+                                                        int hm_w, float beta, Soft* __restrict__ scand /* SOFT only */) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];       // [JN*C] weights, then Best[4][JN]
     float* ws = hsm; Best* red = (Best*)(hsm + JN * C);
     for (int i = threadIdx.x; i < JN * C; i += HEAD_T) ws[i] = w[i];
@@ -266,7 +280,38 @@ __global__ __launch_bounds__(HEAD_T) void k_head_argmax(int HW, int tiles, const
             b = better(b, o);
         }
         if (part == 0) cand[((size_t)crop * tiles + tile) * JN + j] = b;
+        if constexpr (SOFT) {
+            // after the butterfly every lane of the joint holds the tile's maximum: second pass over the same LDS values, weights
+            // relative to it, then plain sums over the 8 lanes (all on the same maximum)
+            float s0 = 0.f, sx = 0.f, sy = 0.f;
+            if (b.v > -__builtin_huge_valf()) {
+#pragma unroll 8
+                for (int q = 0; q < HEAD_T / 8; ++q) {
+                    const int px = q * 8 + part, lp2 = tile * HEAD_T + px;
+                    const float e = __expf(beta * (vs[px * (JN + 1) + j] - b.v));       // pixels past the crop hold -inf: weight 0
+                    const int yy = lp2 / hm_w, xx = lp2 - yy * hm_w;
+                    s0 += e; sx += e * (float)xx; sy += e * (float)yy;
+                }
+            }
+#pragma unroll
+            for (int off = 4; off >= 1; off >>= 1) { s0 += __shfl_xor(s0, off, 64); sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); }
+            if (part == 0) { Soft r; r.m = b.v; r.s = s0; r.sx = sx; r.sy = sy; scand[((size_t)crop * tiles + tile) * JN + j] = r; }
+        }
     }
+}
+// soft-arg-max finish: one lane per joint merges the tiles' partials in order and writes the expected (column, row) through the box;
+// the score is the maximum, as in the hard decode
+__global__ __launch_bounds__(64) void k_softmax_finish(int tiles, const Soft* __restrict__ scand, float beta, int hm_h, int hm_w,
+                                                       const int* __restrict__ view_of, const int* __restrict__ slot_of,
+                                                       const float* __restrict__ boxes, int max_dets, double* __restrict__ det,
+                                                       float* __restrict__ kp) {
+    const int crop = blockIdx.x, j = threadIdx.x;
+    if (j >= J) return;
+    Soft a; a.m = -__builtin_huge_valf(); a.s = 0.f; a.sx = 0.f; a.sy = 0.f;
+    for (int t = 0; t < tiles; ++t) a = soft_merge(a, scand[((size_t)crop * tiles + t) * J + j], beta);
+    double* row = det + ((size_t)view_of[crop] * max_dets + slot_of[crop]) * J * 3;
+    const double inv = a.s > 0.f ? 1.0 / (double)a.s : 0.0;
+    write_keypoint_at(j, (double)a.sy * inv, (double)a.sx * inv, a.m, hm_h, hm_w, boxes + crop * 4, row, kp ? kp + (size_t)crop * J * 3 : nullptr);
 }
 __global__ __launch_bounds__(64) void k_argmax_finish(int tiles, const Best* __restrict__ cand, int hm_h, int hm_w,
                                                       const int* __restrict__ view_of, const int* __restrict__ slot_of,
@@ -305,9 +350,32 @@ extern "C" int pam_head_decode(void* stream, int n, int hm_h, int hm_w, const vo
     if (n == 0) return PAM_OK;
     const int HW = hm_h * hm_w, tiles = (HW + HEAD_T - 1) / HEAD_T;
     const size_t lds = (size_t)J_ * C * sizeof(float) + (size_t)(HEAD_T / 64) * J_ * sizeof(Best) + (size_t)HEAD_T * (J_ + 1) * sizeof(float);
-    hipLaunchKernelGGL((k_head_argmax<PAM_J>), dim3(n * tiles), dim3(HEAD_T), lds, (hipStream_t)stream, HW, tiles,
-                       (const uint16_t*)feat_bf16, C, w, bias, dev_heatmaps_or_null, (Best*)dev_scratch);
+    hipLaunchKernelGGL((k_head_argmax<PAM_J, false>), dim3(n * tiles), dim3(HEAD_T), lds, (hipStream_t)stream, HW, tiles,
+                       (const uint16_t*)feat_bf16, C, w, bias, dev_heatmaps_or_null, (Best*)dev_scratch, hm_w, 0.0f, (Soft*)nullptr);
     hipLaunchKernelGGL(k_argmax_finish, dim3(n), dim3(64), 0, (hipStream_t)stream, tiles, (const Best*)dev_scratch, hm_h, hm_w,
+                       dev_view_of, dev_slot_of, dev_boxes, max_dets, dev_det, dev_kp_xyc);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+// the same pass with a soft-arg-max decode: keypoint = sum_p softmax(beta * heat)_p * (column, row)_p per joint (sub-pixel), score = max
+extern "C" long long pam_head_decode_soft_scratch_bytes(int n, int hm_h, int hm_w) {
+    const long long b = pam_head_decode_scratch_bytes(n, hm_h, hm_w);
+    return b < 0 ? b : b + b / (long long)sizeof(Best) * (long long)sizeof(Soft);
+}
+extern "C" int pam_head_decode_soft(void* stream, int n, int hm_h, int hm_w, const void* feat_bf16, int C, const float* w, const float* bias,
+                                    int J_, float beta, float* dev_heatmaps_or_null, const int32_t* dev_view_of, const int32_t* dev_slot_of,
+                                    const float* dev_boxes, int max_dets, double* dev_det, float* dev_kp_xyc, void* dev_scratch) {
+    if (n < 0 || !feat_bf16 || !w || !dev_view_of || !dev_slot_of || !dev_boxes || !dev_det || !dev_scratch || hm_h <= 0 || hm_w <= 0 ||
+        C <= 0 || C % 8 != 0 || J_ != PAM_J || !(beta > 0.0f))
+        return PAM_E_ARG;
+    if (n == 0) return PAM_OK;
+    const int HW = hm_h * hm_w, tiles = (HW + HEAD_T - 1) / HEAD_T;
+    const size_t lds = (size_t)J_ * C * sizeof(float) + (size_t)(HEAD_T / 64) * J_ * sizeof(Best) + (size_t)HEAD_T * (J_ + 1) * sizeof(float);
+    Best* cand = (Best*)dev_scratch;
+    Soft* scand = (Soft*)(cand + (size_t)n * tiles * J_);                 // 16-byte records behind the 8-byte ones (n * tiles * 17 * 8 is a multiple of 8)
+    hipLaunchKernelGGL((k_head_argmax<PAM_J, true>), dim3(n * tiles), dim3(HEAD_T), lds, (hipStream_t)stream, HW, tiles,
+                       (const uint16_t*)feat_bf16, C, w, bias, dev_heatmaps_or_null, cand, hm_w, beta, scand);
+    hipLaunchKernelGGL(k_softmax_finish, dim3(n), dim3(64), 0, (hipStream_t)stream, tiles, (const Soft*)scand, beta, hm_h, hm_w,
                        dev_view_of, dev_slot_of, dev_boxes, max_dets, dev_det, dev_kp_xyc);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

@@ -376,25 +376,33 @@ class HRNetPose(object):
         if rc != 0:
             raise _lib.PamError('pam_decode_heatmaps failed: %d' % rc)
 
+    soft_beta = None        # None: hard arg-max decode (the parity mode).  A float > 0: soft-arg-max with that inverse temperature
+                            # (sub-pixel keypoints = softmax(beta * heat-map)-weighted mean position; confidence = the maximum).
+
     def head_decode(self, f, view_of, slot_of, boxes, det, kp=None, heat=None, n=None):
-        """Final 1x1 convolution + arg-max decode in one pass over the features f (N,48,h,w channels-last bf16): det rows as
-        ``decode``; the heat-maps are written only when ``heat`` (N,17,h,w float32 channels-last) is given.  n: decode only the
-        first n crops of f."""
+        """Final 1x1 convolution + arg-max decode (soft-arg-max when ``self.soft_beta`` is set) in one pass over the features f
+        (N,48,h,w channels-last bf16): det rows as ``decode``; the heat-maps are written only when ``heat`` (N,17,h,w float32
+        channels-last) is given.  n: decode only the first n crops of f."""
         nf, c, h, w = f.shape
         n = nf if n is None else n
         assert f.is_contiguous(memory_format=torch.channels_last) and f.dtype == torch.bfloat16 and n <= nf
-        need = int(self.lib.pam_head_decode_scratch_bytes(n, h, w))
+        soft = self.soft_beta is not None
+        need = int((self.lib.pam_head_decode_soft_scratch_bytes if soft else self.lib.pam_head_decode_scratch_bytes)(n, h, w))
         if getattr(self, '_hd_scratch', None) is None or self._hd_scratch.numel() < need:
             self._hd_scratch = torch.empty((max(need, 1),), dtype=torch.uint8, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.pam_head_decode(C.c_void_p(st), n, h, w, C.c_void_p(f.data_ptr()), c, C.c_void_p(self.head_w.data_ptr()),
-                                      C.c_void_p(self.head_b.data_ptr()), self.head_w.shape[0],
-                                      C.c_void_p(heat.data_ptr()) if heat is not None else None,
-                                      C.c_void_p(view_of.data_ptr()), C.c_void_p(slot_of.data_ptr()), C.c_void_p(boxes.data_ptr()),
-                                      det.shape[1], C.c_void_p(det.data_ptr()), C.c_void_p(kp.data_ptr()) if kp is not None else None,
-                                      C.c_void_p(self._hd_scratch.data_ptr()))
+        head = (C.c_void_p(st), n, h, w, C.c_void_p(f.data_ptr()), c, C.c_void_p(self.head_w.data_ptr()),
+                C.c_void_p(self.head_b.data_ptr()), self.head_w.shape[0])
+        tail = (C.c_void_p(heat.data_ptr()) if heat is not None else None,
+                C.c_void_p(view_of.data_ptr()), C.c_void_p(slot_of.data_ptr()), C.c_void_p(boxes.data_ptr()),
+                det.shape[1], C.c_void_p(det.data_ptr()), C.c_void_p(kp.data_ptr()) if kp is not None else None,
+                C.c_void_p(self._hd_scratch.data_ptr()))
+        if soft:
+            rc = self.lib.pam_head_decode_soft(*(head + (C.c_float(float(self.soft_beta)),) + tail))
+        else:
+            rc = self.lib.pam_head_decode(*(head + tail))
         if rc != 0:
-            raise _lib.PamError('pam_head_decode failed: %d' % rc)
+            raise _lib.PamError('pam_head_decode%s failed: %d' % ('_soft' if soft else '', rc))
 
     # -- the reference-shaped entry point ------------------------------------------------------------------------------
     def predict(self, person_bbox_list, batch_size=20, conf_threshold=0.4):

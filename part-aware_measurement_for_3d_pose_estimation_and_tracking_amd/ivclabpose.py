@@ -104,6 +104,11 @@ class ivclabpose(object):
                                         model_name=_cfg(self.pose_detector, 'MODEL_NAME'),
                                         resolution=tuple(_cfg(self.pose_detector, 'RESOLUTION')), hrpose_args=gpu_args,
                                         device=device, max_dets=max_dets)
+            # optional key (not in the reference's YAMLs): SOFT_ARGMAX_BETA > 0 switches the decode from the hard arg-max (parity mode)
+            # to the soft-arg-max of pam_head_decode_soft with that inverse temperature
+            sb = self.pose_detector.get('SOFT_ARGMAX_BETA') if isinstance(self.pose_detector, dict) else getattr(self.pose_detector, 'SOFT_ARGMAX_BETA', None)
+            if sb:
+                self.pose_model.soft_beta = float(sb)
             print("Pose Detector : ", _cfg(self.pose_detector, 'NAME'))
         if self.person_matcher is None:
             print("Person Matcher : Close.")

@@ -266,3 +266,62 @@ def test_head_decode_fused_vs_two_kernels(net):
             assert torch.equal(det2[0, 0], exp[0]) and float(det2[1:].abs().max()) == 0.0
         finally:
             net.head_w, net.head_b = old_w, old_b
+
+
+@pytest.mark.gpu
+def test_soft_argmax_decode_vs_torch(net):
+    """pam_head_decode_soft: per joint the softmax(beta * heat-map)-weighted mean (column, row), mapped through the box like the hard
+    decode; confidence = the maximum.  Against float64 torch on the heat-maps the same pass writes (sub-pixel positions to 1e-3 px of
+    the heat-map grid), over ragged last tiles and several betas; a large beta reproduces the hard arg-max keypoints; a constant map
+    gives the centre of the heat-map."""
+    dev = net.device
+    g = torch.Generator().manual_seed(23)
+    old = (net.head_w, net.head_b, net.soft_beta)
+    try:
+        for (n, h, w) in [(4, 96, 72), (3, 7, 5), (2, 33, 17)]:
+            f = torch.randn((n, 48, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+            wt = (torch.randn((17, 48), generator=g) * 0.2).to(dev); b = torch.randn(17, generator=g).to(dev)
+            wt[3] = 0.0                                                # joint 3: constant map
+            net.head_w, net.head_b = wt.contiguous(), b.contiguous()
+            view_of = torch.arange(n, dtype=torch.int32, device=dev) % 3
+            slot_of = torch.arange(n, dtype=torch.int32, device=dev) // 3
+            boxes = (torch.rand((n, 4), generator=g) * 300 + 20).to(dev)
+            ys = torch.arange(h, dtype=torch.float64, device=dev)[:, None].expand(h, w).reshape(-1)
+            xs = torch.arange(w, dtype=torch.float64, device=dev)[None, :].expand(h, w).reshape(-1)
+            for beta in (0.7, 4.0, 25.0):
+                net.soft_beta = beta
+                det = torch.zeros((3, 4, 17, 3), dtype=torch.float64, device=dev)
+                kp = torch.zeros((n, 17, 3), dtype=torch.float32, device=dev)
+                heat = torch.zeros((n, 17, h, w), dtype=torch.float32, device=dev).contiguous(memory_format=torch.channels_last)
+                net.head_decode(f, view_of, slot_of, boxes, det, kp, heat=heat)
+                torch.cuda.synchronize()
+                hm = heat.double().reshape(n, 17, h * w)
+                p = torch.softmax(beta * hm, dim=2)
+                ey, ex = (p * ys).sum(2), (p * xs).sum(2)                  # (n, 17) expected row / column
+                for i in range(n):
+                    bx = boxes[i].double()
+                    want_y = ey[i] / h * bx[3] + bx[1]; want_x = ex[i] / w * bx[2] + bx[0]
+                    got = det[int(view_of[i]), int(slot_of[i])]
+                    tol_y, tol_x = 1e-3 * float(bx[3]) / h + 1e-4, 1e-3 * float(bx[2]) / w + 1e-4
+                    assert float((got[:, 0] - want_y).abs().max()) <= tol_y and float((got[:, 1] - want_x).abs().max()) <= tol_x, (n, h, w, beta, i)
+                    assert torch.equal(got[:, 2].float(), hm[i].max(1).values.float())
+                    assert torch.allclose(kp[i][:, 0].double(), got[:, 1], atol=1e-4) and torch.allclose(kp[i][:, 1].double(), got[:, 0], atol=1e-4)
+                # constant map: centre of the grid
+                got3 = det[0, 0, 3]
+                assert abs(float(got3[0]) - ((h - 1) / 2.0 / h * float(boxes[0, 3]) + float(boxes[0, 1]))) < 1e-2
+            # large beta -> hard arg-max, wherever the maximum stands clear of the runner-up (weight of everything else < e^-40)
+            net.soft_beta = 4.0e4
+            det_s = torch.zeros((3, 4, 17, 3), dtype=torch.float64, device=dev)
+            net.head_decode(f, view_of, slot_of, boxes, det_s)
+            net.soft_beta = None
+            det_h = torch.zeros((3, 4, 17, 3), dtype=torch.float64, device=dev)
+            net.head_decode(f, view_of, slot_of, boxes, det_h)
+            torch.cuda.synchronize()
+            top2 = hm.topk(2, dim=2).values
+            clear = (top2[:, :, 0] - top2[:, :, 1]) > 1e-3                 # (n, 17)
+            assert int(clear.sum()) > n * 8
+            for i in range(n):
+                a_, b_ = det_s[int(view_of[i]), int(slot_of[i])], det_h[int(view_of[i]), int(slot_of[i])]
+                assert float((a_ - b_)[clear[i]].abs().max()) < 1e-3, (n, h, w, i)
+    finally:
+        net.head_w, net.head_b, net.soft_beta = old
