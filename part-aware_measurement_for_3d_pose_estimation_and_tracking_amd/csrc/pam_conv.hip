@@ -919,12 +919,15 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
 // Cin 96 stays on k_conv3x3: its streamed form (96-channel slabs, 160 workgroups) is as fast alone (12.9 vs 13.0 us) but 3-5 % slower
 // end to end -- a 150 KB workgroup shuts the other branches out of its CU, and the 48 x 36 layers have enough tiles to fill the chip.
 static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax, int& ntw) {
-    if (Cin != 192 && Cin != 384) return false;
+    // layer1 / transition1 of HRNet (64 -> 64 and 256 -> 48 at 96 x 72: ReLU layers; the detector's 64- and 256-channel 3x3 layers have
+    // other widths and a leaky activation and stay on k_conv3x3): two rounds of 480 workgroups, still 24 -> 16 us and 59 -> 30 us
+    const bool l1 = (Cin == 64 && Cout == 64) || (Cin == 256 && Cout == 48);
+    if (Cin != 192 && Cin != 384 && !l1) return false;
 #ifdef PAM_DIAG
-    static const int mask = getenv("PAM_C3S_MASK") ? atoi(getenv("PAM_C3S_MASK")) : 6;       // tuning hook: 2 = Cin 192, 4 = 384
-    if (!(mask & (Cin == 192 ? 2 : 4))) return false;
+    static const int mask = getenv("PAM_C3S_MASK") ? atoi(getenv("PAM_C3S_MASK")) : 14;      // tuning hook: 2 = Cin 192, 4 = 384, 8 = 64 / 256
+    if (!(mask & (Cin == 192 ? 2 : (Cin == 384 ? 4 : 8)))) return false;
 #endif
-    const int PW = W + 2, smax = 320, pcap = 384;
+    const int PW = W + 2, smax = 320, pcap = l1 ? 448 : 384;
     // rows per tile: the height that costs the fewest M tiles over the image (a tile always multiplies whole 64-slot wave shares, 3 to
     // 5 of them, and a ragged last tile multiplies as much as a full one); ties go to the taller tile = fewer workgroups
     TH = 0; mt = 0; pmax = 0;
@@ -932,13 +935,13 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
     for (int t = (H < smax / PW ? H : smax / PW); t >= 1; --t) {
         const int sl = t * PW, np = (t + 2) * PW;
         if (np > pcap) continue;
-        // the instantiated (M tiles per wave, patch slots) shapes: (3, 192), (4, 320), (5, 384) -- the smallest that holds the tile
+        // the instantiated (M tiles per wave, patch slots) shapes: (3, 192), (4, 320), (5, 384 | 448) -- the smallest that holds the tile
         const int m = (sl <= 192 && np <= 192) ? 3 : ((sl <= 256 && np <= 320) ? 4 : 5);
         const long cost = (long)((H + t - 1) / t) * m;
-        if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : 384); }
+        if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : (np <= 384 ? 384 : 448)); }
     }
     if (TH < 1) return false;
-    const int bn = 64;
+    const int bn = Cout == 48 ? 48 : 64;
     if (Cout % bn != 0) return false;
     ntw = bn / 16;
     return true;
@@ -959,11 +962,25 @@ static int launch_c3s_one(hipStream_t s, const C3Args& a) {
     hipLaunchKernelGGL((k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>), dim3(a.tiles_y * a.N, a.Cout / (16 * NTW)), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
-static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt) {
+static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, int pmax) {
 #ifdef PAM_DIAG
     static const int nbuf = getenv("PAM_C3S_NBUF") ? atoi(getenv("PAM_C3S_NBUF")) : 0;       // tuning hook
     if (Cin == 384 && ntw == 4 && mt == 3 && nbuf == 2) return launch_c3s_one<384, 4, 3, 192, 2>(s, a);
 #endif
+    if (Cin == 64 || Cin == 256) {                       // layer1 / transition1: every (M tiles, patch) shape the pick can return for them
+        switch ((Cin == 64 ? 0 : 10) + (pmax == 448 ? 6 : mt)) {
+            case 3: return launch_c3s_one<64, 4, 3, 192, 2>(s, a);
+            case 4: return launch_c3s_one<64, 4, 4, 320, 2>(s, a);
+            case 5: return launch_c3s_one<64, 4, 5, 384, 2>(s, a);
+            case 6: return launch_c3s_one<64, 4, 5, 448, 2>(s, a);
+            case 13: return launch_c3s_one<256, 3, 3, 192, 3>(s, a);
+            case 14: return launch_c3s_one<256, 3, 4, 320, 2>(s, a);
+            case 15: return launch_c3s_one<256, 3, 5, 384, 2>(s, a);
+            case 16: return launch_c3s_one<256, 3, 5, 448, 2>(s, a);
+        }
+        return PAM_E_ARG;
+    }
+    if (pmax == 448) return PAM_E_ARG;
     switch (Cin * 100 + ntw * 10 + mt) {
         case 19243: return launch_c3s_one<192, 4, 3, 192, 3>(s, a);
         case 19244: return launch_c3s_one<192, 4, 4, 320, 2>(s, a);
@@ -1329,7 +1346,7 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
             c.dbg = g_c3_stamps ? 64 : 0; c.stamps = g_c3_stamps;
 #endif
             CONV_KIND(PAM_CONV_KERNEL_3X3S);
-            return launch_c3s((hipStream_t)stream, c, Cin, ntw, mt);
+            return launch_c3s((hipStream_t)stream, c, Cin, ntw, mt, pmax);
         }
     }
     const bool classic = tile_cfg == -2;                 // -2: the classic kernels (k_conv3x3 / k_conv_igemm), automatic tiles
