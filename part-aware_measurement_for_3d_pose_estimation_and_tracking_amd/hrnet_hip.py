@@ -170,13 +170,16 @@ class ConvEngine(object):
         if x.device.type == 'meta':
             return y
         act = self.ACT[relu] | (4 if (res_after_act and res is not None) else 0)
-        wimg = op.image(h, w, classic=(self.tile_cfg != -1)) if (in_cs == cin and relu_from == 0) else None
+        # the streamed kernels (k_conv3x3s / k_conv_gs) take the activation codes 0 / 1 only: leaky / shortcut-after-activation layers
+        # (the detector's) ask for the classic kernels and the classic weight image
+        tile_cfg = -2 if (self.tile_cfg == -1 and act > 1) else self.tile_cfg
+        wimg = op.image(h, w, classic=(tile_cfg != -1)) if (in_cs == cin and relu_from == 0) else None
         st = torch.cuda.current_stream(x.device).cuda_stream
         launch = lambda: self.lib.pam_conv2d_nhwc_bf16_ex(
             C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
             C.c_void_p(wimg.data_ptr()) if wimg is not None else None,
             C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None,
-            C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad, act, self.tile_cfg, in_cs, relu_from)
+            C.c_void_p(y.data_ptr()), n, h, w, op.cin, op.cout, op.kh, op.kw, op.stride, op.pad, act, tile_cfg, in_cs, relu_from)
         rc = launch()
         if rc != 0:
             raise _lib.PamError('pam_conv2d_nhwc_bf16 failed (%d) for %s' % (rc, (x.shape, op.cout, op.kh, op.stride)))

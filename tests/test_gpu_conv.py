@@ -169,3 +169,30 @@ def test_channel_sliced_operands_and_partial_relu():
     ref = torch.relu(base.float() + wide[:, 48:96].float() + F.interpolate(coarse[:, 48:96].float(), scale_factor=2, mode='nearest'))
     torch.cuda.synchronize()
     assert torch.equal(out, ref.to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+def test_leaky_layer_of_a_streamed_shape_takes_the_classic_kernel():
+    """A 3x3 layer whose shape the streamed kernel would take (Cin 384, e.g. YOLOv3-tiny's 384 -> 256 after its route) but with a leaky
+    activation: the host asks for the classic kernel and image (tile_cfg -2), the result matches torch."""
+    from pam import _lib, hrnet_hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    conv = nn.Conv2d(384, 256, 3, 1, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (384 * 9)) ** 0.5)
+        conv.bias.copy_(torch.randn(256, generator=g))
+    op = hrnet_hip.PackedConv(conv, dev)
+    x = torch.randn((2, 384, 13, 13), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
+    e.lib = _lib.load(); e.device = dev; e.tile_cfg = -1
+    assert e.lib.pam_conv3x3_layout(13, 13, 384, 256) == 64
+    y = e.conv(op, x, relu='leaky')
+    assert e.lib.pam_conv_last_kernel() in (0, 1)                      # a classic kernel (k_conv_igemm here: k_conv3x3<384> has no leaky epilogue)
+    wq = conv.weight.detach().to(torch.bfloat16).float().to(dev)
+    ref = F.leaky_relu(F.conv2d(x.float(), wq, conv.bias.detach().to(dev), 1, 1), 0.1)
+    torch.cuda.synchronize()
+    err = (y.float() - ref).abs()
+    assert bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all()), float(err.max())
+    y2 = e.conv(op, x, relu=True)
+    assert e.lib.pam_conv_last_kernel() == 2                           # k_conv3x3s
