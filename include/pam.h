@@ -65,9 +65,11 @@ typedef struct PamOutLayout {
     int32_t int_words;      /* int32 words per scene  */
     int32_t dbl_words;      /* float64 words per scene */
     /* int32 section: header then per-track blocks (list order = the reference's self.tracks order) */
-    int32_t hdr_words;      /* [0]=n_tracks [1]=status bits OF THIS FRAME: 1 = out of track slots, 2 = out of hypothesis slots,
-                             * 4 = an assignment problem was infeasible, 8 = a device-side detection count outside [0, max_dets]
-                             * was clamped (pam_frame_dev) [2]=frame_id [3]=n_hyp (debug) */
+    int32_t hdr_words;      /* [0]=n_tracks [1]=status word: bits 0-15 = status bits OF THIS FRAME: 1 = out of track slots, 2 = out of
+                             * hypothesis slots, 4 = an assignment problem was infeasible, 8 = a device-side detection count outside
+                             * [0, max_dets] was clamped (pam_frame_dev); bits 16-31 = the same bits OR-ed over EVERY frame since
+                             * pam_create / pam_reset (sticky: a host that decodes only the last record of a run still sees them)
+                             * [2]=frame_id [3]=n_hyp (debug) */
     int32_t trk_words;      /* words per track block */
     /* track block: 0 id,1 state,2 hits,3 age,4 time_since_update,5 emitted,6 n_2d_views,7 V (views offered to the
      * newest pose),8 history length,9 newest pose time, then order[n_views], matched_det[n_views] (index of the
@@ -110,6 +112,10 @@ int pam_out_layout(const PamHandle* h, PamOutLayout* out);
  * pam_fetch: async copy of the device output record to (pinned) host memory on `stream`. */
 int pam_frame(PamHandle* h, int frame_id, const int32_t* n_det, const double* det, int32_t* out_i, double* out_d);
 int pam_frame_dev(PamHandle* h, void* stream, int frame_id, const int32_t* dev_n_det, const double* dev_det);
+/* the same step on VIEW-SHARDED input, read in place (no unpack kernel, no copies): dev_records = the buffer the all-gather of the
+ * ranks' send buffers filled (pam_allgather_keypoints' dev_recv; record layout there), dev_view_row[v] (n_views int32) = which of its
+ * records holds view v.  One scene per handle. */
+int pam_frame_dev_views(PamHandle* h, void* stream, int frame_id, const double* dev_records, const int32_t* dev_view_row);
 int pam_fetch(PamHandle* h, void* stream, int32_t* host_out_i, double* host_out_d);
 int pam_sync(PamHandle* h, void* stream);
 
@@ -177,6 +183,10 @@ int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames /*de
 int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw, int hm_h, int hm_w,
                         const int32_t* dev_view_of, const int32_t* dev_slot_of, const float* dev_boxes,
                         int max_dets, double* dev_det, float* dev_kp_xyc /*optional n*17*3 (x,y,conf) or NULL*/);
+/* measurement aid, not part of the path: one wave spins `microseconds` and writes {delta shader cycles (s_memtime), delta 100 MHz
+ * ticks (s_memrealtime)} to dev_out2 -> shader clock [MHz] = 100 * out[0] / out[1] at that point of the stream (bench.py records it
+ * right before and right after the timed region). */
+int pam_clock_probe(void* stream, unsigned long long* dev_out2, int microseconds);
 
 /* ---- HRNet conv stack (a1) as hand-written MFMA kernels -------------------------------------------------------
  * pam_conv2d_nhwc_bf16: NHWC bf16 convolution (KH,KW in {1,3}; stride 1/2; Cin % 8 == 0; Cout % 48 == 0 or % 64 == 0) as an
@@ -206,7 +216,10 @@ int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
 /* 0: w_img of this layer is the classic per-chunk image described above; BN > 0: the layer runs on the streamed kernel k_conv3x3s
  * (Cin 192 / 384 at tile_cfg == -1) with slabs of BN output channels and w_img must be [Cout/BN][Cin/32][9 taps][BN rows][4][8]
  * bf16: chunk c, tap t, row r (same row -> channel rule as above) holds input channels 32*c + 8*g .. + 8 of that tap in its 16-byte
- * piece g ^ ((r >> 1) & 2).  tile_cfg == -2 forces the classic kernel (and the classic image) for such a layer. */
+ * piece g ^ ((r >> 1) & 2).  tile_cfg == -2 forces the classic kernel (and the classic image) for such a layer.  BN > 0 is only
+ * returned for shapes the streamed kernel is instantiated for (64-channel slabs for Cin 64 / 192 / 384, the 48-channel slab for
+ * 256 -> 48); the streamed kernel takes activation codes 0 / 1 only, so a layer with a Darknet code (relu > 1) must be packed in the
+ * classic layout and called with tile_cfg == -2 (tile_cfg == -1 with a streamed image and relu > 1 returns PAM_E_ARG). */
 int pam_conv3x3_layout(int H, int W, int Cin, int Cout);
 /* which kernel the calling thread's last pam_conv2d_nhwc_bf16[_ex] call launched (labels for per-kernel profiles) */
 #define PAM_CONV_KERNEL_IGEMM 0   /* k_conv_igemm */
@@ -248,8 +261,10 @@ int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDes
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before
  * the cross-view match every rank contributes its views' keypoint records and receives everyone's: ONE all-gather per frame, enqueued on
- * the stream the decode ran on.  Record per view: [n_det, det[max_dets*17*3]] float64 (rows (y, x, score)); rows_per_rank = the largest
- * number of views any rank owns (unused rows are padding); dev_recv holds world * rows_per_rank records, rank-major.
+ * the stream the decode ran on.  Record per view: (max_dets + 1) x 17*3 float64 -- max_dets detection rows (y, x, score), i.e. exactly
+ * what pam_head_decode writes for that view when it is given max_dets + 1 as its slot stride, then one more row whose FIRST double is
+ * the view's detection count; rows_per_rank = the largest number of views any rank owns (unused records are padding); dev_recv holds
+ * world * rows_per_rank records, rank-major, and is what pam_frame_dev_views reads.
  * The communicator is RCCL's (ncclComm_t); librccl is bound at run time, so single-GPU hosts never need it.  pam_comm_unique_id on one
  * rank -> ship the 128 bytes to the others by any means -> pam_comm_init on every rank (collective). */
 int pam_comm_unique_id(void* id128);

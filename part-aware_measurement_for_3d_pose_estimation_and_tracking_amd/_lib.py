@@ -69,6 +69,7 @@ _SIGS = {
     'pam_out_layout': (_I, [_P, C.POINTER(PamOutLayout)]),
     'pam_frame': (_I, [_P, _I, _P, _P, _P, _P]),
     'pam_frame_dev': (_I, [_P, _P, _I, _P, _P]),
+    'pam_frame_dev_views': (_I, [_P, _P, _I, _P, _P]),
     'pam_fetch': (_I, [_P, _P, _P, _P]),
     'pam_sync': (_I, [_P, _P]),
     'pam_op_project': (_I, [_P, _I, _I, _P, _P]),
@@ -84,6 +85,7 @@ _SIGS = {
     'pam_op_hyp_cost': (_I, [_P, _I, _P, _P, _I, _P, _P, _P]),
     'pam_preprocess_crops': (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P]),
     'pam_decode_heatmaps': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
+    'pam_clock_probe': (_I, [_P, _P, _I]),
     'pam_conv2d_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 11),
     'pam_conv2d_nhwc_bf16_ex': (_I, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 13),
     'pam_conv3x3_slab': (_I, [_I, _I, _I, _I]),
@@ -239,6 +241,11 @@ class Handle(object):
         self._chk(self.lib.pam_frame_dev(self._h, C.c_void_p(stream), int(frame_id), C.c_void_p(dev_n_det_ptr),
                                          C.c_void_p(dev_det_ptr)))
 
+    def frame_dev_views(self, stream, frame_id, dev_records_ptr, dev_view_row_ptr):
+        """The frame on the all-gathered per-view records (ViewGather.recv), read in place through the row map."""
+        self._chk(self.lib.pam_frame_dev_views(self._h, C.c_void_p(stream), int(frame_id), C.c_void_p(dev_records_ptr),
+                                               C.c_void_p(dev_view_row_ptr)))
+
     def fetch(self, stream, out_i=None, out_d=None):
         out_i = self.out_i if out_i is None else out_i
         out_d = self.out_d if out_d is None else out_d
@@ -268,7 +275,10 @@ class Handle(object):
                 time2d=b[L.off_time2d:L.off_time2d + self.C].copy(),
                 nviews=b[L.off_nviews:L.off_nviews + PAM_J].copy(),
                 pose3d=dd[:PAM_J * 3].reshape(PAM_J, 3).copy(), velocity=dd[PAM_J * 3:].reshape(PAM_J, 3).copy()))
-        return dict(n_tracks=n, status=int(oi[1]), frame_id=int(oi[2]), n_hyp=int(oi[3]), clocks=od[:4].copy(), tracks=tracks)
+        # status word: bits 0-15 = this frame's bits, bits 16-31 = OR of every frame's bits since create / reset (include/pam.h)
+        w = int(oi[1]) & 0xffffffff
+        return dict(n_tracks=n, status=w & 0xffff, status_sticky=(w >> 16) & 0xffff, frame_id=int(oi[2]), n_hyp=int(oi[3]),
+                    clocks=od[:4].copy(), clocks_all=od[:L.dbl_hdr_words].copy(), tracks=tracks)
 
     # ---- per-operator entry points (parity tests) -------------------------------------------------------------------
     def op_project(self, cid, poses3d):

@@ -944,6 +944,9 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
     const int bn = Cout == 48 ? 48 : 64;
     if (Cout % bn != 0) return false;
     ntw = bn / 16;
+    // only shapes launch_c3s() instantiates: 64-channel slabs for Cin 192 / 384 (and 64 -> 64), the 48-channel slab for 256 -> 48;
+    // anything else (e.g. Cin 192 -> Cout 48) stays on k_conv3x3 / the implicit GEMM and keeps the classic weight image
+    if (Cin == 256 ? ntw != 3 : ntw != 4) return false;
     return true;
 }
 extern "C" int pam_conv3x3_layout(int H, int W, int Cin, int Cout) {

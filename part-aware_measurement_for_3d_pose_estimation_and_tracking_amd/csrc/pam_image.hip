@@ -404,3 +404,21 @@ extern "C" int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmap
                            dev_view_of, dev_slot_of, dev_boxes, max_dets, dev_det, dev_kp_xyc);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
+
+// ---- measurement aid (bench.py): the shader clock the chip holds at this point of a stream ---------------------------------
+// One wave spins for `ticks` periods of the 100 MHz reference counter and reports (delta s_memtime, delta s_memrealtime): shader
+// clock [MHz] = 100 * d_memtime / d_memrealtime (MI355X guide, 'DVFS give-back' item 6).  Enqueued right before and right after the
+// timed region it shows whether a run sat in a lower power state; it carries no data of the path.
+__global__ __launch_bounds__(64) void k_clock_probe(unsigned long long* out, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    out[0] = c1 - c0; out[1] = r1 - r0;
+}
+extern "C" int pam_clock_probe(void* stream, unsigned long long* dev_out2, int microseconds) {
+    if (!dev_out2 || microseconds < 1 || microseconds > 100000) return PAM_E_ARG;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_out2, (unsigned long long)microseconds * 100ull);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}

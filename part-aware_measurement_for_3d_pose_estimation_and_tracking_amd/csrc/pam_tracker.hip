@@ -37,7 +37,7 @@ struct Carver {
 
 // ---- per-scene tracker state (HBM resident across frames) -------------------------------------------------------
 struct SceneState {
-    int* hdr;        // [0] n_tracks [1] next_id [2] status [3] used_lo [4] used_hi
+    int* hdr;        // [0] n_tracks [1] next_id [2] status of this frame [3] used_lo [4] used_hi [5] OR of every frame's status since pam_reset
     int* order;      // list position -> slot (the reference's self.tracks order)
     int *track_id, *hits, *age, *tsu, *already, *state, *p2d_n, *h_head, *h_len, *jv_V;
     int* p2d_order;  // [slot][k]   camera ids in dict-insertion order (Appendix A-5)
@@ -143,6 +143,8 @@ struct FrameArgs {
     char* state; size_t state_stride;
     char* ws; size_t ws_stride;
     const int* n_det; const double* det;
+    const int* view_row;   // view-sharded input (pam_frame_dev_views): det = the all-gathered records, view v's record is row view_row[v];
+                           // record = (MAXP + 1) x 51 doubles: MAXP detection rows, then the view's detection count in the first double
     int* out_i; double* out_d;
     PamOutLayout ol;
     int frame_id;
@@ -157,7 +159,8 @@ __device__ __forceinline__ double now_s() { return (double)__builtin_amdgcn_s_me
 // The per-frame step: IterativeTracker.tracking (IterativeTracker.py:115-180) + output collection
 // (ivclabpose.py:259-287).  One 256-thread workgroup per scene; phases separated by workgroup barriers.
 // =====================================================================================================================
-__global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
+template <int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
     const Dims d = A.d;
     const int C = d.C, MAXP = d.MAXP, MAXT = d.MAXT, HCAP = d.HCAP, MAXH = d.MAXH;
     const int sidx = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -182,20 +185,23 @@ __global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
     const PamParams& prm = *A.prm;
     const CamSet cs = A.cs;
     const int frame = A.frame_id;
-    const int* n_det = A.n_det + (size_t)sidx * C;
-    const double* det = A.det + (size_t)sidx * C * MAXP * J3;
+    const int* vrow = A.view_row;                                       // non-null: records gathered from the ranks (one scene)
+    const int* n_det = vrow ? nullptr : A.n_det + (size_t)sidx * C;
+    const double* det = vrow ? A.det : A.det + (size_t)sidx * C * MAXP * J3;
+    const size_t recd = vrow ? (size_t)(MAXP + 1) * J3 : (size_t)MAXP * J3;
     int* out_i = A.out_i + (size_t)sidx * A.ol.int_words;
     double* out_d = A.out_d + (size_t)sidx * A.ol.dbl_words;
-#define DET(v, k) (det + ((size_t)(v) * MAXP + (k)) * J3)
+#define DET(v, k) (det + (size_t)(vrow ? vrow[v] : (v)) * recd + (size_t)(k) * J3)
+#define NDET_RAW(v) (vrow ? (int)det[(size_t)vrow[v] * recd + (size_t)MAXP * J3] : n_det[v])
     const int nT = st.hdr[0];
     // device-side counts are not validated by the host (pam_frame_dev): clamp them so that no index leaves det / ws.taken
-#define NDET(v) min(max(n_det[v], 0), MAXP)
+#define NDET(v) min(max(NDET_RAW(v), 0), MAXP)
 
     // ---- P0: add_age, time gaps (IterativeTracker.py:126-129) -------------------------------------------------------
     if (tid == 0) {
         out_d[0] = now_s(); ws.misc[1] = nT;
         int bad = 0;
-        for (int v = 0; v < C; ++v) bad |= (n_det[v] < 0 || n_det[v] > MAXP);
+        for (int v = 0; v < C; ++v) { const int nv = NDET_RAW(v); bad |= (nv < 0 || nv > MAXP); }
         st.hdr[2] = bad ? ST_NDET_CLAMPED : 0;                       // the status word is per frame (out_i[1]); nothing sticks
     }
     __syncthreads();
@@ -603,7 +609,10 @@ __global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
             if (st.state[s] == DELETED) used &= ~(1ull << s); else st.order[m++] = s;
         }
         st.hdr[0] = m; st.hdr[3] = (int)(unsigned)(used & 0xffffffffull); st.hdr[4] = (int)(unsigned)(used >> 32);
-        out_i[0] = m; out_i[1] = st.hdr[2]; out_i[2] = frame; out_i[3] = ws.misc[0];
+        // status word: bits 0-15 = this frame, bits 16-31 = OR over every frame since pam_create / pam_reset (a host that
+        // only decodes the last record of a run still sees an overflow raised in any earlier frame)
+        st.hdr[5] |= st.hdr[2];
+        out_i[0] = m; out_i[1] = (st.hdr[2] & 0xffff) | (st.hdr[5] << 16); out_i[2] = frame; out_i[3] = ws.misc[0];
     }
     __syncthreads();
 
@@ -638,6 +647,8 @@ __global__ __launch_bounds__(1024) void k_frame(FrameArgs A) {
         for (size_t o = (size_t)threadIdx.x * 4; o < st_ints; o += (size_t)blockDim.x * 4) *(int*)(st_glob + o) = *(const int*)(st_lds + o);
     }
 #undef DET
+#undef NDET
+#undef NDET_RAW
 }
 
 // =====================================================================================================================
@@ -871,18 +882,21 @@ extern "C" int pam_out_layout(const PamHandle* h, PamOutLayout* out) {
     return PAM_OK;
 }
 
-static int launch_frame(PamHandle* h, hipStream_t s, int frame_id, const int* d_ndet, const double* d_det) {
+static int launch_frame(PamHandle* h, hipStream_t s, int frame_id, const int* d_ndet, const double* d_det, const int* d_view_row = nullptr) {
     if (!h->cams_set) { h->err = "pam_set_cameras has not been called"; return PAM_E_STATE; }
     FrameArgs A;
     A.d = h->d; A.cs = camset(h); A.prm = h->d_prm;
     A.state = h->d_state; A.state_stride = h->state_stride; A.ws = h->d_ws; A.ws_stride = h->ws_stride;
-    A.n_det = d_ndet; A.det = d_det; A.out_i = h->d_out_i; A.out_d = h->d_out_d; A.ol = h->ol; A.frame_id = frame_id;
+    A.n_det = d_ndet; A.det = d_det; A.view_row = d_view_row; A.out_i = h->d_out_i; A.out_d = h->d_out_d; A.ol = h->ol; A.frame_id = frame_id;
     const size_t hot = hot_bytes(h->d) + ((state_int_bytes(h->d) + 15) & ~(size_t)15);
     A.hot_in_lds = hot <= 128 * 1024 ? 1 : 0;
     // one workgroup per scene; many-camera rigs have ~10^4-10^5 independent (track, view pair, joint) items per frame, so
     // they get the largest workgroup (16 waves hide the L2 latency of the pose / fundamental-matrix reads)
     const int block = h->d.C > 8 ? 1024 : BLOCK;
-    hipLaunchKernelGGL(k_frame, dim3(h->d.S), dim3(block), A.hot_in_lds ? hot : 0, s, A);
+    // each workgroup size is its own instantiation with its own __launch_bounds__: under a shared bound of 1024 the 256-thread
+    // form was held to 128 VGPRs (occupancy 4) and spilled 211 SGPRs
+    if (block == 1024) hipLaunchKernelGGL(k_frame<1024>, dim3(h->d.S), dim3(1024), A.hot_in_lds ? hot : 0, s, A);
+    else hipLaunchKernelGGL(k_frame<BLOCK>, dim3(h->d.S), dim3(BLOCK), A.hot_in_lds ? hot : 0, s, A);
     HIPCHK(h, hipGetLastError());
     return PAM_OK;
 }
@@ -891,6 +905,15 @@ extern "C" int pam_frame_dev(PamHandle* h, void* stream, int frame_id, const int
     if (!h) return PAM_E_ARG;
     ARGCHK(h, dev_n_det && dev_det, "null device buffer");
     return launch_frame(h, (hipStream_t)stream, frame_id, dev_n_det, dev_det);
+}
+
+// The frame on view-sharded input: dev_records = the buffer pam_allgather_keypoints (or any all-gather of the ranks' send buffers)
+// filled, dev_view_row[v] = which of its records holds view v.  The kernel reads the records in place: no unpack kernel, no copies.
+extern "C" int pam_frame_dev_views(PamHandle* h, void* stream, int frame_id, const double* dev_records, const int32_t* dev_view_row) {
+    if (!h) return PAM_E_ARG;
+    ARGCHK(h, dev_records && dev_view_row, "null device buffer");
+    ARGCHK(h, h->d.S == 1, "view-sharded input is one scene per handle");
+    return launch_frame(h, (hipStream_t)stream, frame_id, nullptr, dev_records, dev_view_row);
 }
 
 extern "C" int pam_fetch(PamHandle* h, void* stream, int32_t* host_out_i, double* host_out_d) {
@@ -1158,8 +1181,9 @@ extern "C" int pam_allgather_keypoints(PamHandle* h, void* comm, void* stream, c
     if (!h) return PAM_E_ARG;
     ARGCHK(h, comm && dev_send && dev_recv && rows_per_rank >= 1, "null communicator / buffer");
     if (!rccl_load()) { h->err = g_rccl_err; return PAM_E_STATE; }
-    // one record per view: [n_det, det[max_dets * 17 * 3]] float64 (ViewGather's layout); ncclFloat64 = 8
-    const size_t count = (size_t)rows_per_rank * (1 + (size_t)h->d.MAXP * J3);
+    // one record per view: (max_dets + 1) rows of 51 float64 -- the detection rows, then the view's detection count in the first
+    // double of the last row (ViewGather's layout, read in place by pam_frame_dev_views); ncclFloat64 = 8
+    const size_t count = (size_t)rows_per_rank * ((size_t)h->d.MAXP + 1) * J3;
     const int e = g_rccl.AllGather(dev_send, dev_recv, count, 8 /* ncclFloat64 */, comm, (hipStream_t)stream);
     if (e != 0) { h->err = std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"); return PAM_E_HIP; }
     return PAM_OK;

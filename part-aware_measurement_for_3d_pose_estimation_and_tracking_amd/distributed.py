@@ -48,8 +48,11 @@ class AbiComm(object):
 
 
 class ViewGather(object):
-    """Fixed-size padded record per view: [n_det, det[max_dets*17*3]] float64 (float64 keeps caller-supplied keypoints
-    lossless; records decoded from float32 heat-maps are exactly representable)."""
+    """Fixed-size padded record per view, float64 (keeps caller-supplied keypoints lossless; records decoded from float32 heat-maps
+    are exactly representable): (max_dets + 1) rows of 17 x 3 -- the view's detection rows (y, x, score), then one row whose first
+    element is the detection count.  ``send`` IS the decode target of this rank's views (``det_local`` is a view of it: the head +
+    arg-max kernel writes row (view, slot) with a slot stride of max_dets + 1), the all-gather fills ``recv``, and the frame kernel
+    reads ``recv`` in place through ``rows`` (pam_frame_dev_views): per frame the exchange is one count copy + the collective."""
 
     def __init__(self, n_views, max_dets, world, rank, device, group=None, abi=None):
         """abi: (Handle, AbiComm) -> the exchange goes through pam_allgather_keypoints (RCCL called from the library, enqueued on the
@@ -59,24 +62,27 @@ class ViewGather(object):
         self.parts = view_partition(n_views, world)
         self.mine = self.parts[rank]
         self.maxv = max(1, max(len(p) for p in self.parts))
-        self.rec = 1 + max_dets * NUM_JOINTS * 3
-        self.send = torch.zeros((self.maxv, self.rec), dtype=torch.float64, device=device)
-        self.recv = torch.zeros((world * self.maxv, self.rec), dtype=torch.float64, device=device)
+        self.send = torch.zeros((self.maxv, max_dets + 1, NUM_JOINTS, 3), dtype=torch.float64, device=device)
+        # one rank without a communicator: nothing to exchange, the frame kernel reads the send buffer itself
+        self.recv = torch.zeros((world * self.maxv, max_dets + 1, NUM_JOINTS, 3), dtype=torch.float64, device=device) \
+            if (world > 1 or abi is not None) else self.send
+        self.det_local = self.send[:max(1, len(self.mine))]            # contiguous: the leading records
+        self.count_local = self.send[:, max_dets, 0, 0]               # strided view: one count per record
         rows = [0] * n_views
         for r, p in enumerate(self.parts):
             for i, v in enumerate(p):
                 rows[v] = r * self.maxv + i
-        self.rows = torch.tensor(rows, dtype=torch.long, device=device)
-        self.n_det = torch.zeros(n_views, dtype=torch.int32, device=device)
-        self.det = torch.zeros((n_views, max_dets, NUM_JOINTS, 3), dtype=torch.float64, device=device)
+        self.rows = torch.tensor(rows, dtype=torch.int32, device=device)
+        self.rows_long = self.rows.long()
 
-    def gather(self, n_det_local, det_local):
-        """n_det_local (len(mine),) int, det_local (len(mine), max_dets, 17, 3) float64 on this rank's device ->
-        (n_det (C,) int32, det (C, max_dets, 17, 3) float64), identical on every rank."""
+    def exchange(self, n_det_local):
+        """n_det_local (len(mine),) int tensor; the detection rows are already in ``send`` (det_local).  Returns ``recv`` -- every
+        rank's records, rank-major -- identical on every rank; read it through ``rows``."""
         k = len(self.mine)
         if k:
-            self.send[:k, 0] = n_det_local.to(torch.float64)
-            self.send[:k, 1:] = det_local.reshape(k, -1)
+            self.count_local[:k].copy_(n_det_local)                    # int -> float64 in the copy: one small kernel
+        if self.world == 1 and self.abi is None:
+            return self.recv
         if self.abi is not None:
             import ctypes as C
             handle, comm = self.abi
@@ -84,15 +90,19 @@ class ViewGather(object):
                                                     C.c_void_p(self.send.data_ptr()), self.maxv, C.c_void_p(self.recv.data_ptr()))
             if rc != 0:
                 raise RuntimeError('pam_allgather_keypoints failed (%d): %s' % (rc, handle.lib.pam_last_error(handle.raw).decode()))
-            full = self.recv.index_select(0, self.rows)
-        elif self.world > 1:
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-            full = self.recv.index_select(0, self.rows)
         else:
-            full = self.send[:self.C]
-        self.n_det.copy_(full[:, 0].to(torch.int32))
-        self.det.copy_(full[:, 1:].reshape(self.C, self.max_dets, NUM_JOINTS, 3))
-        return self.n_det, self.det
+            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
+        return self.recv
+
+    def gather(self, n_det_local, det_local):
+        """Host-visible form (tests, CPU): n_det_local (len(mine),) int, det_local (len(mine), max_dets, 17, 3) float64 ->
+        (n_det (C,) int32, det (C, max_dets, 17, 3) float64), identical on every rank.  The product path does not unpack: the frame
+        kernel reads ``recv`` through ``rows``."""
+        k = len(self.mine)
+        if k and det_local.data_ptr() != self.send.data_ptr():
+            self.send[:k, :self.max_dets].copy_(det_local.reshape(k, self.max_dets, NUM_JOINTS, 3))
+        full = self.exchange(n_det_local).index_select(0, self.rows_long)
+        return full[:, self.max_dets, 0, 0].to(torch.int32), full[:, :self.max_dets].contiguous()
 
 
 def crop_partition(n_crops, world):
@@ -133,6 +143,15 @@ class CropGather(object):
             torch.index_select(self.recv.view(self.world * self.rows, -1), 0, select, out=self.det.view(self.rows, -1))
             return self.det
         return self.send
+
+
+def check_same_call(n_crops, n_views, device, group=None):
+    """Debug guard of the crop-sharded predict(): raises unless every rank was called with the same number of crops and views."""
+    t = torch.tensor([n_crops, -n_crops, n_views, -n_views], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    lo_n, hi_n, lo_v, hi_v = -int(t[1]), int(t[0]), -int(t[3]), int(t[2])
+    if lo_n != hi_n or lo_v != hi_v:
+        raise RuntimeError('crop-sharded predict() is a collective: ranks passed %d..%d crops in %d..%d views' % (lo_n, hi_n, lo_v, hi_v))
 
 
 def gather_crop_keypoints(kp_local, n_total, world, rank, group=None):

@@ -235,17 +235,23 @@ class HRNetPose(object):
     ``predict(person_bbox_list, batch_size, conf_threshold) -> dump_results`` (ivclabpose.py:131-132,210)."""
 
     def __init__(self, c, nof_joints, checkpoint_path, model_name='HRNet', resolution=(384, 288), hrpose_args=None,
-                 device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16, backend='hip', graph_bucket=4):
+                 device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16, backend='hip', graph_bucket=4,
+                 shard_crops=False, group=None):
         assert model_name == 'HRNet' and int(nof_joints) == 17
         if not torch.cuda.is_available():
             raise RuntimeError('HRNetPose needs a GPU (the preprocessing / decode kernels are HIP only; no CPU fallback)')
         self.lib = _lib.load()
         # hrpose_args: the reference hands HRNetPose every visible GPU (gpu_args.gpus / .device, ivclabpose.py:107-111,131-132) and
-        # lets the backend spread a batch over them inside one process.  Here the unit is one process per GPU: under an initialised
-        # torch.distributed group of W ranks, predict() deals the call's person crops out over the ranks, runs its share on ITS
-        # device (hrpose_args.device if given, else `device`), and ONE all-gather returns every rank the complete dump.
+        # lets the backend spread a batch over them inside one process.  Here the unit is one process per GPU.  shard_crops=True
+        # (what ivclabpose passes when it runs under a torch.distributed job) makes predict() a COLLECTIVE over `group`: every rank
+        # must call it with the SAME person_bbox_list; the call's crops are dealt out over the ranks, each runs its share on ITS
+        # device (hrpose_args.device if given, else `device`) and ONE all-gather returns every rank the complete dump.  The default
+        # is off: a merely initialised process group (a view-sharded host that calls predict() with per-rank inputs) changes nothing.
         import torch.distributed as dist
-        self.world, self.rank = (dist.get_world_size(), dist.get_rank()) if (dist.is_available() and dist.is_initialized()) else (1, 0)
+        self.group = group
+        self.world, self.rank = (1, 0)
+        if shard_crops and dist.is_available() and dist.is_initialized():
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         dv = getattr(hrpose_args, 'device', None) if hrpose_args is not None else None
         if dv is None and isinstance(hrpose_args, dict):
             dv = hrpose_args.get('device')
@@ -445,7 +451,9 @@ class HRNetPose(object):
         kp = torch.empty((n, 17, 3), dtype=torch.float32, device=self.device)
         lo, hi = 0, n
         if self.world > 1:                                # this rank's share of the call's crops (ordered by view, then person)
-            from .distributed import crop_partition
+            from .distributed import crop_partition, check_same_call
+            if os.environ.get('PAM_CHECK_SHARD', '0') == '1':    # debug: a rank with another crop list would hang or mis-assemble the gather
+                check_same_call(n, V, self.device, self.group)
             lo, hi = crop_partition(n, self.world)[self.rank]
         for s in range(lo, hi, batch_size):
             e = min(hi, s + batch_size)
@@ -462,7 +470,7 @@ class HRNetPose(object):
                 self.decode(self.heatmaps(x)[:k], view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
         if self.world > 1:
             from .distributed import gather_crop_keypoints
-            kp = gather_crop_keypoints(kp[lo:hi].contiguous(), n, self.world, self.rank)
+            kp = gather_crop_keypoints(kp[lo:hi].contiguous(), n, self.world, self.rank, self.group)
             # the tracker's device-side input, rebuilt from the gathered rows: (view, slot) <- (y, x, score) as float64
             det[view_of.long(), slot_of.long()] = kp[:, :, [1, 0, 2]].double()
         kp_h = kp.cpu().numpy().astype(np.float64)       # the reference's contract is host lists: one device -> host copy per call
@@ -484,20 +492,56 @@ class DumpResults(list):
 
     def attach(self, det, n_det, poses_host):
         self.device_det, self.device_n_det, self.poses_host = det, n_det, poses_host
-        self._witness = [[(id(it), id(it['keypoints']), it['keypoints'][0], it['keypoints'][-1]) for it in items] for items in self]
+        # complete witness of what the tracker would read from the dicts (ivclabpose._unpack: 'keypoints' AND 'keypoints_score'):
+        # object identities + a hash of all 51 + 17 numbers per person -- an interior edit or a re-scored joint invalidates it
+        self._witness = [[(id(it), id(it['keypoints']), id(it['keypoints_score']),
+                           hash(tuple(it['keypoints'])), hash(tuple(it['keypoints_score']))) for it in items] for items in self]
 
     def device_valid(self):
-        """True while the dicts are the ones predict() returned (same objects, same keypoint lists, end values untouched)."""
+        """True while the dicts are exactly what predict() returned: same objects and every keypoint / keypoints_score value
+        untouched (the tracker reads both, /root/reference/src/ivclabpose.py:236-244).  Any edit -- masking or re-scoring joints
+        between PersonPoseDetect and PersonTrack_Project3DPose -- sends the call through the host dicts again."""
         if self.device_det is None or len(self._witness) != len(self):
             return False
         for items, wit in zip(self, self._witness):
             if len(items) != len(wit):
                 return False
-            for it, (a, b, k0, k1) in zip(items, wit):
-                k = it.get('keypoints')
-                if id(it) != a or id(k) != b or len(k) != 51 or k[0] != k0 or k[-1] != k1:
+            for it, (a, b, c, hk, hs) in zip(items, wit):
+                k, sc = it.get('keypoints'), it.get('keypoints_score')
+                if id(it) != a or id(k) != b or id(sc) != c or len(k) != 51 or len(sc) != 17:
+                    return False
+                if hash(tuple(k)) != hk or hash(tuple(sc)) != hs:
                     return False
         return True
+
+
+def measure_bf16_drift(net, n_crops=2, seed=2):
+    """Self-consistency number of the bf16 conv stack (parity with the authors' backend is unpinned: no weights offline): the same
+    folded weights run as a plain fp32 PyTorch module on the same device (the checker) vs ``net``'s product path, on seeded random
+    crops.  -> relative L2 error of the heat-maps, fraction of (crop, joint) arg-max cells that moved, and the largest move in
+    heat-map cells.  With random weights the heat-maps are nearly flat noise, so the arg-max fraction is a pessimistic figure."""
+    dev = net.device
+    seed_w = int(net.weights.split('=')[1].rstrip(')')) if net.weights.startswith('random') else 0
+    if not net.weights.startswith('random'):
+        raise RuntimeError('measure_bf16_drift rebuilds the fp32 module from the seed; load the checkpoint into both to use it with real weights')
+    ref = fold_batchnorm(init_random(PoseHighResolutionNet(), seed=seed_w)).to(dev).eval()
+    g = torch.Generator().manual_seed(seed)
+    x32 = torch.randn((n_crops, 3, net.resolution[0], net.resolution[1]), generator=g).to(dev)
+    xb = x32.to(torch.bfloat16)
+    x8 = torch.cat([xb, torch.zeros((n_crops, net.in_channels - 3, net.resolution[0], net.resolution[1]), dtype=torch.bfloat16, device=dev)], dim=1) \
+        if net.in_channels > 3 else xb
+    x8 = x8.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        h32 = ref(xb.float())
+        hb = net.heatmaps(x8).float()
+    w = h32.shape[3]
+    a32, ab = h32.flatten(2).argmax(2), hb.flatten(2).argmax(2)
+    moved = (a32 != ab)
+    cells = torch.maximum((a32 // w - ab // w).abs(), (a32 % w - ab % w).abs())
+    return dict(crops=n_crops, rel_l2_err=float((hb - h32).norm() / h32.norm()), argmax_moved_frac=float(moved.float().mean()),
+                argmax_max_cells=int(cells.max()), argmax_mean_cells_when_moved=float(cells[moved].float().mean()) if bool(moved.any()) else 0.0,
+                score_max_abs_err=float((hb.flatten(2).max(2)[0] - h32.flatten(2).max(2)[0]).abs().max()),
+                weights=net.weights, checker='same folded weights as a plain fp32 PyTorch module on the GPU')
 
 
 def smoke_check():

@@ -103,7 +103,8 @@ class ivclabpose(object):
                                         _cfg(self.pose_detector, 'CHECKPOINT_FILE'),
                                         model_name=_cfg(self.pose_detector, 'MODEL_NAME'),
                                         resolution=tuple(_cfg(self.pose_detector, 'RESOLUTION')), hrpose_args=gpu_args,
-                                        device=device, max_dets=max_dets)
+                                        device=device, max_dets=max_dets,
+                                        shard_crops=torch.distributed.is_available() and torch.distributed.is_initialized())
             # optional key (not in the reference's YAMLs): SOFT_ARGMAX_BETA > 0 switches the decode from the hard arg-max (parity mode)
             # to the soft-arg-max of pam_head_decode_soft with that inverse temperature
             sb = self.pose_detector.get('SOFT_ARGMAX_BETA') if isinstance(self.pose_detector, dict) else getattr(self.pose_detector, 'SOFT_ARGMAX_BETA', None)

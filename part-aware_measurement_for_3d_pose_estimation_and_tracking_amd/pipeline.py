@@ -19,7 +19,7 @@ class FramePipeline(object):
                  rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False, net=None, exchange='torch'):
         """shard: 'views' -- rank owns whole camera views (pose_step / track_step take view-local inputs); 'crops' -- the
         frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices).
-        overlap_tracker (crops mode): exchange + tracker kernel + fetch of frame t run on their own stream, under the conv
+        overlap_tracker (either mode): exchange + tracker kernel + fetch of frame t run on their own stream, under the conv
         stack of frame t+1 (the tracker is one workgroup per scene; it rides on CUs the conv kernels leave idle)."""
         self.device = torch.device('cuda:%d' % device)
         torch.cuda.set_device(self.device)
@@ -45,13 +45,14 @@ class FramePipeline(object):
         self.gather = ViewGather(self.C, max_dets, world, rank, self.device, group, abi=(self.handle, self.comm) if self.comm else None)
         self.crop_gather = CropGather(self.C, max_dets, world, rank, self.device, group) if shard == 'crops' else None
         self.mine = self.gather.mine
-        # decode target: this rank's views only, (len(mine), max_dets, 17, 3)
-        self.det_local = torch.zeros((max(1, len(self.mine)), max_dets, NUM_JOINTS, 3), dtype=torch.float64, device=self.device)
+        # decode target: this rank's views only -- the leading records of the exchange's send buffer, (len(mine), max_dets + 1, 17, 3):
+        # slot stride max_dets + 1, the extra row carries the view's detection count (ViewGather)
+        self.det_local = self.gather.det_local
         L = self.handle.layout
         self.out_i = torch.zeros((1, L.int_words), dtype=torch.int32).pin_memory()
         self.out_d = torch.zeros((1, L.dbl_words), dtype=torch.float64).pin_memory()
         self.ev = None
-        self.track_stream = torch.cuda.Stream(self.device) if (overlap_tracker and shard == 'crops') else None
+        self.track_stream = torch.cuda.Stream(self.device) if overlap_tracker else None
         self.ev_pose, self.ev_track, self._track_pending = torch.cuda.Event(), torch.cuda.Event(), False
 
     def stream_ptr(self):
@@ -69,20 +70,40 @@ class FramePipeline(object):
         f = self.net.features(x)
         if time_events is not None:
             time_events[1].record()
+        self.wait_track()                               # the previous frame's exchange / tracker read the buffer decode writes
         self.net.head_decode(f, view_local, slot_of, boxes, self.det_local)
 
-    def track_step(self, frame_id, n_det_local, det_local, fetch=True):
-        """Exchange (if sharded) + fused tracker kernel on the gathered keypoints; async fetch of the record."""
-        n_det, det = self.gather.gather(n_det_local, det_local)
-        st = self.stream_ptr()
-        self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
-        if fetch:
-            self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
+    def write_local(self, rows):
+        """Copy keypoint rows (len(mine), max_dets, 17, 3) into this rank's records, ordered behind the previous frame's readers."""
+        self.wait_track()
+        self.det_local[:, :self.max_dets].copy_(rows.reshape(-1, self.max_dets, NUM_JOINTS, 3)[:self.det_local.shape[0]])
+
+    def track_step(self, frame_id, n_det_local, det_local=None, fetch=True):
+        """Exchange (if sharded) + fused tracker kernel on the gathered records, read in place through the row map
+        (pam_frame_dev_views); async fetch of the record.  det_local: None / ``self.det_local`` = the rows are already in the send
+        buffer (decode, write_local); any other tensor is copied in first."""
+        if det_local is not None and det_local.data_ptr() != self.det_local.data_ptr():
+            self.write_local(det_local)
+
+        def issue(st):
+            recv = self.gather.exchange(n_det_local)
+            self.handle.frame_dev_views(st, frame_id, recv.data_ptr(), self.gather.rows.data_ptr())
+            if fetch:
+                self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
+        if self.track_stream is None:
+            issue(self.stream_ptr())
+            return
+        self.ev_pose.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.track_stream):
+            self.track_stream.wait_event(self.ev_pose)
+            issue(self.track_stream.cuda_stream)
+            self.ev_track.record(self.track_stream)
+        self._track_pending = True
 
     # -- crop-balanced sharding ----------------------------------------------------------------------------------------------
     def wait_track(self):
-        """Order the caller's stream behind the previous frame's exchange / tracker (they read ``crop_gather.send``): call before
-        ANY write to that buffer -- decode, or a caller that fills it itself."""
+        """Order the caller's stream behind the previous frame's exchange / tracker (they read ``crop_gather.send`` / the view
+        records): call before ANY write to that buffer -- decode, or a caller that fills it itself."""
         if self._track_pending:
             torch.cuda.current_stream(self.device).wait_event(self.ev_track)
 
@@ -130,12 +151,13 @@ class FramePipeline(object):
 
     def results(self, strict=True):
         """Synchronise and decode the last fetched record.  strict: a non-zero status word (capacity overflow, infeasible
-        assignment, clamped detection count -- include/pam.h) raises instead of passing silently into the caller's numbers."""
+        assignment, clamped detection count -- include/pam.h) IN ANY FRAME since the handle was created or reset (the sticky half of
+        the word) raises instead of passing silently into the caller's numbers."""
         if self.track_stream is not None:
             self.track_stream.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
         rec = self.handle.decode(0, self.out_i.numpy(), self.out_d.numpy())
-        if strict and rec['status'] != 0:
-            raise _lib.PamError('tracker status 0x%x on frame %d (1 track slots, 2 hypothesis slots, 4 infeasible assignment, 8 clamped '
-                                'detection count)' % (rec['status'], rec['frame_id']))
+        if strict and (rec['status'] | rec['status_sticky']) != 0:
+            raise _lib.PamError('tracker status 0x%x on frame %d, 0x%x over the run (1 track slots, 2 hypothesis slots, 4 infeasible '
+                                'assignment, 8 clamped detection count)' % (rec['status'], rec['frame_id'], rec['status_sticky']))
         return rec

@@ -41,6 +41,11 @@ def _worker(rank, world, port, C, max_dets, ret):
         mine = g.mine
         nd, dd = g.gather(torch.tensor(n_det[t, mine], dtype=torch.int32), torch.tensor(det[t][mine]).reshape(len(mine), max_dets, 17, 3))
         ok &= bool(np.array_equal(nd.numpy(), n_det[t])) and bool(np.array_equal(dd.numpy(), det[t]))
+        # what the frame kernel reads in place (pam_frame_dev_views): view v's record is recv[rows[v]] -- max_dets detection rows, then
+        # the count in the first double of the extra row
+        for v in range(C):
+            rec = g.recv[int(g.rows[v])].numpy()
+            ok &= bool(np.array_equal(rec[:max_dets], det[t][v])) and rec[max_dets, 0, 0] == n_det[t, v]
     ret[rank] = ok
     dist.barrier()
     dist.destroy_process_group()

@@ -240,3 +240,81 @@ def test_facade_vs_oracle_on_fresh_stress_sequences(size, seed, kw):
             assert np.abs(np.asarray(a[3]) - np.asarray(b[3])).max() < 1e-6, t
             n_out += len(a[5])
     assert n_out > 100
+
+
+def test_status_word_is_sticky_across_frames(lib):
+    """An overflow raised in an EARLY frame must still be visible in the LAST record of a run (bench.py / FramePipeline.results decode
+    only that one): bits 0-15 of the status word are this frame's, bits 16-31 the OR over every frame since create / reset."""
+    seq = synth.make_sequence('S2', n_frames=12, seed=5)
+    cams = O.make_cameras(seq['calib'])
+    cfg = dict(synth.MATCHER_CFG['Shelf']); conf = cfg.pop('CONF_THRESHOLD')
+    h = lib.Handle(5, lib.make_params(cfg, conf), max_dets=8, max_tracks=2, n_scenes=1)       # 4 persons, 2 track slots
+    h.set_cameras(np.stack([c.P for c in cams]), np.stack([c.F for c in cams]), np.stack([c.RK_INV for c in cams]),
+                  np.stack([c.position for c in cams]))
+    nd, dd = synth.pack_frames(seq['frames'], 8)
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    seen = []
+    for t in range(12):
+        n_t = torch.tensor(nd[t] if t < 3 else np.zeros_like(nd[t]), dtype=torch.int32, device='cuda')      # later frames: nothing to spawn
+        d_t = torch.tensor(dd[t], dtype=torch.float64, device='cuda')
+        h.frame_dev(st, t, n_t.data_ptr(), d_t.data_ptr())
+        h.fetch(st); h.sync(st)
+        rec = h.decode(0)
+        seen.append((rec['status'], rec['status_sticky']))
+    assert seen[0][0] & 1, seen                      # the first frame runs out of track slots
+    assert seen[-1][0] == 0, seen                    # the last frame is clean ...
+    assert seen[-1][1] & 1, seen                     # ... and still reports the earlier overflow
+    h.reset()
+    n_t = torch.zeros(5, dtype=torch.int32, device='cuda')
+    h.frame_dev(st, 0, n_t.data_ptr(), d_t.data_ptr()); h.fetch(st); h.sync(st)
+    rec = h.decode(0)
+    assert rec['status'] == 0 and rec['status_sticky'] == 0
+    h.close()
+
+
+def test_pcp_gate_through_the_hip_path():
+    """north_star's first parity clause, asserted (not implied): the golden Shelf-like sequence goes through pam.ivclabpose (k_frame),
+    the 3D poses are converted and scored by the restated evaluator exactly as /root/reference/src/evalmodel.py:120-206 does, and
+    `check_result` + the PCP table must equal what the REFERENCE's Evaluate3DPose_PCP produced on the reference's own tracker output
+    (tests/golden/pcp_S2.npz; tools/make_goldens.py adds seeded 5 cm noise to the predictions so that the table is non-trivial -- the
+    same noise stream is added here)."""
+    from pam import evaluation as E
+    from pam.ivclabpose import ivclabpose
+
+    def factory(cfg, conf):
+        return ivclabpose(person_detector={'NAME': ''}, pose_detector=None,
+                          person_matcher=dict(cfg, NAME='Iterative'), conf_threshold=conf)
+    z = G.load('pcp_S2.npz')
+    F = int(z['n_frames'])
+    skipped = set(int(t) for t in z['skipped'])
+    mine = {}
+    tr = G.load('trace_S2.npz')
+    c = G.cameras('S2')
+    cfg = dict(synth.MATCHER_CFG[str(tr['meta.dataset'])]); conf = cfg.pop('CONF_THRESHOLD')
+    model = factory(cfg, conf)
+    model.GetCameraParameters({'P': c['P'], 'K': c['K'], 'RT': c['RT']}, 0, 0)
+    for t, views in enumerate(G.trace_frames(tr)):
+        if not any(len(v) for v in views):
+            continue
+        pbl, dr = synth.to_dump_results(views)
+        out = model.PersonTrack_Project3DPose(t, pbl, dr, 'SVD')
+        mine[t] = np.asarray(out[3], dtype=np.float64).reshape(-1, 3, 17)
+    rng = np.random.default_rng(7)                                  # the generator of make_goldens.make_pcp, drawn in the same order
+    preds = {}
+    for t in range(F):
+        if t in skipped:
+            preds[t] = []
+            continue
+        p = mine.get(t, np.zeros((0, 3, 17)))
+        assert p.shape == z['pred.%d' % t].shape, (t, p.shape)
+        preds[t] = p + rng.normal(0, 0.05, p.shape)
+        np.testing.assert_allclose(preds[t], z['pred.%d' % t], rtol=0, atol=1e-6)
+    gt = z['gt']
+    actors = [[(None if np.isnan(gt[a, f]).all() else gt[a, f]) for f in range(gt.shape[1])] for a in range(gt.shape[0])]
+    check, rows = E.evaluate_pcp(z['eval_ranges'].tolist(), preds, actors, verbose=False)
+    assert np.array_equal(check, z['check_result'])                 # every (frame, actor, limb) decision identical
+    for r, rr in zip(rows[1:], z['table'][1:]):
+        assert r[0] == str(rr[0])
+        for a, b in zip(r[1:], rr[1:]):
+            assert abs(float(a) - float(b)) < 1e-9, (r, rr)

@@ -109,3 +109,69 @@ def test_allgather_keypoints_through_the_c_abi():
         for ta, tb in zip(a['tracks'], b['tracks']):
             assert ta['track_id'] == tb['track_id'] and ta['emitted'] == tb['emitted'] and np.array_equal(ta['pose3d'], tb['pose3d'])
     abi.comm.close()
+
+
+def _views_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)          # two ranks on ONE device: RCCL refuses that, gloo carries the gather
+    from pam import synth
+    from pam.pipeline import FramePipeline
+    seq, cams, cfg, conf, meta = _rig('S2')
+    md = 8
+    n_det_all, det_all = synth.pack_frames(seq['frames'], md)
+    ovl = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False, shard='views', overlap_tracker=True,
+                        world=world, rank=rank)
+    dev, mine = ovl.device, ovl.mine
+    nd = [torch.tensor(n_det_all[t][mine], dtype=torch.int32, device=dev) for t in range(len(seq['frames']))]
+    dd = [torch.tensor(det_all[t][mine], dtype=torch.float64, device=dev) for t in range(len(seq['frames']))]
+    ballast = torch.randn((2048, 2048), device=dev)
+    for t in range(len(seq['frames'])):                                    # no host synchronisation between frames
+        _ = ballast @ ballast
+        ovl.write_local(dd[t]); ovl.track_step(t, nd[t])
+    last = ovl.results()
+    ser = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False, shard='views', overlap_tracker=False)
+    for t in range(len(seq['frames'])):
+        ser.track_step(t, torch.tensor(n_det_all[t], dtype=torch.int32, device=dev), torch.tensor(det_all[t], dtype=torch.float64, device=dev))
+        ref = ser.results()
+    ok = last['n_tracks'] == ref['n_tracks'] and last['frame_id'] == ref['frame_id'] and ref['n_tracks'] > 0
+    for ta, tb in zip(ref['tracks'], last['tracks']):
+        ok &= ta['track_id'] == tb['track_id'] and ta['hits'] == tb['hits'] and ta['age'] == tb['age'] and ta['emitted'] == tb['emitted']
+        ok &= bool(np.array_equal(ta['pose3d'], tb['pose3d'])) and bool(np.array_equal(ta['velocity'], tb['velocity']))
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_sharded_overlapped_pipeline_two_ranks_one_device():
+    """The N > 1 default of bench.py -- camera views partitioned over the ranks, ONE all-gather per frame, the frame kernel reading the
+    gathered records in place, exchange + tracker of frame t on their own stream under frame t + 1 -- with two ranks (gloo, both on
+    this device), K frames and no host synchronisation: every rank's final record equals the single-process serial run's."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_views_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
+
+
+def test_view_records_in_place_match_packed_input():
+    """pam_frame_dev_views (records + row map) and pam_frame_dev (packed n_det / det) are the same step: identical records."""
+    from pam import synth
+    from pam.pipeline import FramePipeline
+    seq, cams, cfg, conf, meta = _rig('S2')
+    md = 8
+    n_det_all, det_all = synth.pack_frames(seq['frames'], md)
+    a = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False, shard='views')
+    b = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False, shard='crops')
+    dev = a.device
+    for t in range(len(seq['frames'])):
+        nd = torch.tensor(n_det_all[t], dtype=torch.int32, device=dev)
+        dd = torch.tensor(det_all[t], dtype=torch.float64, device=dev)
+        a.track_step(t, nd, dd); ra = a.results()
+        st = b.stream_ptr()
+        b.handle.frame_dev(st, t, nd.data_ptr(), dd.data_ptr()); b.handle.fetch(st, b.out_i.numpy(), b.out_d.numpy()); rb = b.results()
+        assert np.array_equal(a.out_i.numpy(), b.out_i.numpy())
+        k = a.handle.layout.dbl_hdr_words
+        assert np.array_equal(a.out_d.numpy()[:, k:], b.out_d.numpy()[:, k:])
