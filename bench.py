@@ -674,13 +674,14 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
         # slower (measured on the 256-core GPU host: one batch-20 forward took 209 s at 256 threads vs 1.5 s at 16).  A ONE-crop probe
         # at all cores against 16 threads decides whether the full batch is run at all cores; either way the batch is really run
         # (never extrapolated) at the thread counts below and the fastest is the baseline.
-        def one_crop(thr):
+        def one_crop(thr, warm):
             torch.set_num_threads(thr)
-            model(x[:1])
+            if warm:
+                model(x[:1])
             t0 = time.perf_counter(); model(x[:1]); return time.perf_counter() - t0
         small = min(16, avail)
-        p_small = one_crop(small)
-        p_all = one_crop(avail) if avail > small else p_small
+        p_small = one_crop(small, True)
+        p_all = one_crop(avail, False) if avail > small else p_small      # a single forward: at 256 threads even one crop takes ~10 s
         probe = {'one_crop_s_at_%d_threads' % small: p_small, 'one_crop_s_at_%d_threads' % avail: p_all}
         best = None
         if p_all <= 2.0 * p_small:
