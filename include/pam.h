@@ -258,6 +258,21 @@ int pam_basic_block_nhwc_bf16(void* stream, int n_branches, const PamBlockDesc* 
 /* waves: 4 = 256-thread workgroups, two per CU (C = 48 / 96 only), 8 = 512-thread workgroups, 0 = 4 when every branch allows it */
 int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* blocks, int waves);
 
+/* ---- the pointwise tail of a layer1 Bottleneck as ONE launch (row a1; csrc/pam_pw.hip) ------------------------------------------
+ * X = ReLU(W3 . y2 [+ Wd . x0] + bias3 [+ residual]);  y1 = ReLU(W1 . X + bias1)   per pixel, NHWC bf16:
+ * y2 (n_pixels x 64): the block's 3x3 output; x0 (n_pixels x 64, or NULL): the first block's input, whose 1x1 downsample convolution is
+ * a second K range of the same product (bias3 then = conv3's + the downsample's); residual (n_pixels x 256, or NULL; not with x0);
+ * out_x (n_pixels x 256); w1_img / bias1 / out_y1 (n_pixels x 64): the NEXT block's conv1, or all NULL.  HRNet-W48's widths only.
+ * w3_img [S][256][64] bf16 (S = 1, or 2 with x0): chunk c = K source c; row 64 sl + 16 jt + qq (qq < 16) = output channel
+ *   64 sl + 16 (qq >> 2) + 4 jt + (qq & 3); the row's 16-byte piece at position p holds K values 8 q .. 8 q + 7, q = p ^ ((row >> 1) & 7).
+ * w1_img [4][64][64] bf16: chunk sl = input channels 64 sl .. + 63; row 16 jt + qq = output channel 16 (qq >> 2) + 4 jt + (qq & 3);
+ *   piece p holds, with q = p ^ ((row >> 1) & 7), h = q >> 2, g = q & 3, the input channels 64 sl + 16 g + 8 h .. + 7.
+ * tile_cfg: 16-pixel tiles per wave tile (1..3), <= 0 = automatic.  replaces: conv3 + bn3 + residual + relu and the next conv1 + bn1 +
+ * relu of the official Bottleneck (the HRNet backend is absent from the reference: call sites /root/reference/src/ivclabpose.py:131-132,210). */
+int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const void* x0, const void* residual, const void* w3_img,
+                                  const float* bias3, const void* w1_img, const float* bias1, void* out_x, void* out_y1,
+                                  long long n_pixels, int tile_cfg);
+
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before
  * the cross-view match every rank contributes its views' keypoint records and receives everyone's: ONE all-gather per frame, enqueued on

@@ -98,6 +98,7 @@ _SIGS = {
     'pam_basic_block_chunk_layout': (_I, [_I, _P]),
     'pam_basic_block_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_basic_block_nhwc_bf16_ex': (_I, [_P, _I, _P, _I]),
+    'pam_bottleneck_tail_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I]),
     'pam_comm_unique_id': (_I, [_P]),
     'pam_comm_init': (_I, [C.POINTER(_P), _I, _I, _P, _I]),
     'pam_comm_destroy': (_I, [_P]),

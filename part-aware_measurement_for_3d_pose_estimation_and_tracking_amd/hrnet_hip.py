@@ -139,6 +139,41 @@ class PackedBlock(object):
         self.c1 = self.c2 = None            # the unfused PackedConv pair (fallback for shapes the fused kernel does not take)
 
 
+class PackedTail(object):
+    """The pointwise tail of a layer1 Bottleneck packed for ``pam_bottleneck_tail_nhwc_bf16`` (csrc/pam_pw.hip; layouts: include/pam.h):
+    conv3 (64 -> 256) [+ the first block's 1x1 downsample as a second K chunk] and, optionally, the NEXT block's conv1 (256 -> 64)."""
+
+    def __init__(self, conv3, down, conv1_next, device):
+        assert conv3.weight.shape == (256, 64, 1, 1) and (down is None or down.weight.shape == (256, 64, 1, 1))
+        assert conv1_next is None or conv1_next.weight.shape == (64, 256, 1, 1)
+        zb = lambda cv: cv.bias.detach().float() if cv.bias is not None else torch.zeros(cv.weight.shape[0])
+        R = torch.arange(256)
+        rem = R % 64
+        ch3 = 64 * (R // 64) + 16 * ((rem % 16) >> 2) + 4 * (rem // 16) + (rem & 3)                   # LDS row -> output channel
+        q3 = torch.arange(8)[None, :] ^ ((R >> 1) & 7)[:, None]                                    # [row][physical piece] -> logical piece
+        srcs = [conv3] + ([down] if down is not None else [])
+        img = torch.zeros((len(srcs), 256, 8, 8), dtype=torch.float32)
+        for c, cv in enumerate(srcs):
+            w = cv.weight.detach().float().reshape(256, 64)[ch3].reshape(256, 8, 8)                # [row][logical piece][8]
+            img[c] = torch.gather(w, 1, q3[:, :, None].expand(256, 8, 8))
+        self.w3 = img.to(torch.bfloat16).to(device).contiguous()
+        self.b3 = (zb(conv3) + (zb(down) if down is not None else 0)).to(device).contiguous()
+        self.S = len(srcs)
+        self.w1 = self.b1 = None
+        if conv1_next is not None:
+            R1 = torch.arange(64)
+            ch1 = 16 * ((R1 % 16) >> 2) + 4 * (R1 // 16) + (R1 & 3)
+            q1 = torch.arange(8)[None, :] ^ ((R1 >> 1) & 7)[:, None]                               # [row][physical piece] -> logical piece q
+            w = conv1_next.weight.detach().float().reshape(64, 256)[ch1]                           # [row][input channel]
+            im1 = torch.zeros((4, 64, 8, 8), dtype=torch.float32)
+            e = torch.arange(8)
+            for sl in range(4):
+                cin = 64 * sl + 16 * (q1 & 3)[:, :, None] + 8 * (q1 >> 2)[:, :, None] + e[None, None, :]   # [row][piece][8] input channel
+                im1[sl] = torch.gather(w, 1, cin.reshape(64, 64)).reshape(64, 8, 8)
+            self.w1 = im1.to(torch.bfloat16).to(device).contiguous()
+            self.b1 = zb(conv1_next).to(device).contiguous()
+
+
 class ConvEngine(object):
     """Kernel launchers shared by the pose network (HipHRNet) and the person detector (yolov3.HipDarknet)."""
     count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
@@ -227,6 +262,38 @@ class ConvEngine(object):
                        sum(2 * (2 * x.numel() + 2 * 9 * o.c * o.c) + 8 * o.c for o, x in zip(ops, xs)),
                        sum(2 * 2 * x.numel() * 9 * o.c for o, x in zip(ops, xs)), launch)
         return ys
+
+    def bottleneck_tail(self, op, y2, x0=None, res=None, tile_cfg=0):
+        """X = ReLU(conv3(y2) [+ downsample(x0)] [+ res]); y1 = ReLU(conv1_next(X)) in one launch -> (X, y1 or None)."""
+        n, c, h, w = y2.shape
+        assert c == 64 and (x0 is None) == (op.S == 1), (y2.shape, op.S)
+        X = torch.empty((n, 256, h, w), dtype=torch.bfloat16, device=y2.device, memory_format=torch.channels_last)
+        Y = torch.empty((n, 64, h, w), dtype=torch.bfloat16, device=y2.device, memory_format=torch.channels_last) if op.w1 is not None else None
+        if self._keep is not None:
+            self._keep.append(X)
+            if Y is not None:
+                self._keep.append(Y)
+        M = n * h * w
+        nbytes = 2 * (y2.numel() + (x0.numel() if x0 is not None else 0) + (res.numel() if res is not None else 0) + X.numel() +
+                      (Y.numel() if Y is not None else 0) + op.S * 256 * 64 + (64 * 256 if op.w1 is not None else 0)) + 4 * (256 + (64 if op.w1 is not None else 0))
+        flops = 2 * M * (op.S * 64 * 256 + (256 * 64 if op.w1 is not None else 0))
+        if self.count is not None:
+            self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
+        if y2.device.type == 'meta':
+            return X, Y
+        for t in (y2, x0, res):
+            assert t is None or t.is_contiguous(memory_format=torch.channels_last)
+        launch = lambda: self.lib.pam_bottleneck_tail_nhwc_bf16(
+            C.c_void_p(torch.cuda.current_stream(y2.device).cuda_stream), C.c_void_p(y2.data_ptr()),
+            C.c_void_p(x0.data_ptr()) if x0 is not None else None, C.c_void_p(res.data_ptr()) if res is not None else None,
+            C.c_void_p(op.w3.data_ptr()), C.c_void_p(op.b3.data_ptr()),
+            C.c_void_p(op.w1.data_ptr()) if op.w1 is not None else None, C.c_void_p(op.b1.data_ptr()) if op.w1 is not None else None,
+            C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()) if Y is not None else None, M, tile_cfg)
+        rc = launch()
+        if rc != 0:
+            raise _lib.PamError('pam_bottleneck_tail_nhwc_bf16 failed (%d) for %s' % (rc, tuple(y2.shape)))
+        self._prof_add(y2, 'k_pw2 bottleneck tail', (n, h, w, op.S, res is not None, op.w1 is not None), nbytes, flops, launch)
+        return X, Y
 
     def upsample_add(self, base, terms, shifts, relu):
         n, c, h, w = base.shape
@@ -360,6 +427,10 @@ class HipHRNet(ConvEngine):
         self.conv2 = P(m.conv2)
         self.layer1 = [dict(c1=P(b.conv1), c2=P(b.conv2), c3=P(b.conv3),
                             down=P(b.downsample[0]) if b.downsample is not None else None) for b in m.layer1]
+        # the same blocks for the fused pointwise tail: tail b = conv3_b [+ downsample_0] + residual + ReLU, then conv1_{b+1} + ReLU
+        l1 = list(m.layer1)
+        self.tails = [PackedTail(b.conv3, b.downsample[0] if b.downsample is not None else None,
+                                 l1[i + 1].conv1 if i + 1 < len(l1) else None, device) for i, b in enumerate(l1)]
         self.t1 = [P(m.transition1[0][0]), P(m.transition1[1][0][0])]
         self.t2 = P(m.transition2[2][0][0])
         self.t3 = P(m.transition3[3][0][0])
@@ -600,6 +671,8 @@ class HipHRNet(ConvEngine):
         self._keep = []
         return self._features(x8)
 
+    fuse_tail = True            # layer1: conv3 + residual + next conv1 of every Bottleneck in one launch (csrc/pam_pw.hip)
+    tail_cfg = 0                # its wave-tile size (0 = automatic)
     stop_after = None           # diagnostics (tools/stage_times.py): 'stem' | 'layer1' | 'stage2' | 'stage3' -> the forward ends there
 
     def _end(self, xs):
@@ -614,11 +687,21 @@ class HipHRNet(ConvEngine):
         x = self.conv(self.conv2, x, relu=True)
         if self.stop_after == 'stem':
             return x
-        for b in self.layer1:
-            r = x if b['down'] is None else self.conv(b['down'], x)
-            y = self.conv(b['c1'], x, relu=True)
-            y = self.conv(b['c2'], y, relu=True)
-            x = self.conv(b['c3'], y, res=r, relu=True)
+        if self.fuse_tail:
+            # layer1 as 1 + 4 x 2 launches: conv1 of the first block, then per block the 3x3 and ONE pointwise-tail launch (conv3 + residual
+            # / downsample + ReLU + the next block's conv1): the 256-channel tensor is written once and read once per block
+            x0, res = x, None
+            y = self.conv(self.layer1[0]['c1'], x0, relu=True)
+            for i, b in enumerate(self.layer1):
+                y2 = self.conv(b['c2'], y, relu=True)
+                x, y = self.bottleneck_tail(self.tails[i], y2, x0 if i == 0 else None, res, self.tail_cfg)
+                res = x
+        else:
+            for b in self.layer1:
+                r = x if b['down'] is None else self.conv(b['down'], x)
+                y = self.conv(b['c1'], x, relu=True)
+                y = self.conv(b['c2'], y, relu=True)
+                x = self.conv(b['c3'], y, res=r, relu=True)
         if self.stop_after == 'layer1':
             return x
         self._barrier()                                               # branch streams must see layer1's output
