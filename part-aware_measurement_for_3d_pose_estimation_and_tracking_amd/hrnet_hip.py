@@ -517,8 +517,122 @@ class HipHRNet(ConvEngine):
             for st in self.side:
                 st.wait_stream(cur)
 
+    # ---- dependency-precise schedule (dag = True) -------------------------------------------------------------------------------
+    # Instead of joining all branch streams once per module, every tensor that crosses streams carries the event recorded behind its
+    # producer, and a consumer stream waits for exactly the tensors it reads: sum i waits only for ITS terms and branch i of the next
+    # module starts behind sum i, while other branches' chains and fuse convolutions are still running.  Captured into the hipGraph these
+    # waits are plain edges.  (All side streams are forked from the caller's stream at the start of the forward and joined at its end.)
+    dag = True
+
+    def _sobj(self, b):
+        l = self.lane_of[b]
+        return torch.cuda.current_stream(self.device) if (l == 0 or not self.multi_stream) else self.side[l - 1]
+
+    def _mark(self, t, b):
+        """t was just produced on branch stream b."""
+        if self.multi_stream:
+            ev = torch.cuda.Event()
+            ev.record(self._sobj(b))
+            self._evt[id(t)] = (ev, self.lane_of[b], t)       # the tensor is kept so that its id cannot be reused within the forward
+
+    def _need(self, t, b):
+        """branch stream b is about to read t."""
+        if self.multi_stream:
+            e = self._evt.get(id(t))
+            if e is not None and e[1] != self.lane_of[b]:
+                self._sobj(b).wait_event(e[0])
+
+    def _hr_module_dag(self, mod, xs):
+        xs = list(xs)
+        fuse = mod['fuse']
+        nb = len(mod['branches'])
+        terms = [dict() for _ in fuse]                    # terms[i][j] = (tensor or channel slice, shift, base tensor that carries the event)
+        n0 = (xs[0][2] if isinstance(xs[0], tuple) else xs[0]).shape[0]
+        fmax = self.fuse_max_branches if self.fuse_max_branches is not None else (3 if n0 >= 96 else 1)
+        grouped = []
+        if self.fuse_blocks:
+            for b in range(nb):
+                shp = xs[b][2].shape if isinstance(xs[b], tuple) else xs[b].shape
+                cb = mod['branches'][b][0][0].cin
+                hb, wb = (shp[2], shp[3]) if not isinstance(xs[b], tuple) else ((shp[2] + 2 - 3) // xs[b][1].stride + 1, (shp[3] + 2 - 3) // xs[b][1].stride + 1)
+                if mod['fused'][b] is not None and len(grouped) == b and len(grouped) < min(fmax, _lib.PAM_BLOCK_MAX_BRANCHES) and \
+                        self.lib.pam_basic_block_rows(cb, hb, wb, 0) > 0:
+                    grouped.append(b)
+
+        def transition(b):
+            if isinstance(xs[b], tuple):                  # a branch this stage creates: its transition conv runs on its own stream
+                with torch.cuda.stream(self._stream(b)):
+                    self._need(xs[b][2], b)
+                    xs[b] = self.conv(xs[b][1], xs[b][2], relu=True)
+                    self._mark(xs[b], b)
+        if grouped:                                       # one grouped launch per block level on the caller's stream (= branch 0's)
+            for b in grouped:
+                transition(b)
+            for b in grouped:
+                self._need(xs[b], 0)
+            ys = [xs[b] for b in grouped]
+            for k in range(len(mod['fused'][0])):
+                ys = self.basic_blocks([mod['fused'][b][k] for b in grouped], ys, self.fuse_waves)
+            for b, y in zip(grouped, ys):
+                xs[b] = y
+                self._mark(y, 0)
+        for b in [q for q in self.order if q < nb]:
+            blocks = mod['branches'][b] if b not in grouped else []
+            transition(b)
+            with torch.cuda.stream(self._stream(b)):
+                x = xs[b]
+                self._need(x, b)
+                for c1, c2 in blocks:
+                    y = self.conv(c1, x, relu=True)
+                    x = self.conv(c2, y, res=x, relu=True)
+                xs[b] = x
+                # the 1x1 up-convolutions first: they feed the FINER outputs, whose next chains are the longest
+                mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up) else None
+                if mu is not None:
+                    y = self.conv(mu['op'], x)
+                    self._mark(y, b)
+                    for i, off, c, sh in mu['parts']:
+                        terms[i][b] = (y[:, off:off + c], sh, y)
+                for i, row in enumerate(fuse):
+                    f = row[b] if b < len(row) else None
+                    if f is not None and f[0] == 'up' and mu is None:
+                        y = self.conv(f[1], x)
+                        self._mark(y, b)
+                        terms[i][b] = (y, f[2], y)
+                mg = mod['merged'].get(b) if self.merge_fuse else None
+                heads = {}
+                if mg is not None:                        # first conv of all down chains from this branch in one launch
+                    yh = self.conv(mg['op'], x, relu=True, relu_from=mg['relu_from'])
+                    self._mark(yh, b)
+                    heads = {i: yh[:, off:off + c] for i, off, c, _ in mg['parts']}
+                for i, row in enumerate(fuse):
+                    f = row[b] if b < len(row) else None
+                    if f is None or f[0] == 'up':
+                        continue
+                    t, ops = (heads[i], f[1][1:]) if i in heads else (x, f[1])
+                    k0 = len(f[1]) - len(ops)
+                    base = yh if (i in heads and not ops) else None
+                    for k, op in enumerate(ops):
+                        t = self.conv(op, t, relu=(k0 + k < len(f[1]) - 1))
+                    if base is None:
+                        self._mark(t, b); base = t
+                    terms[i][b] = (t, 0, base)
+        # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order, on stream i
+        out = [None] * len(fuse)
+        for i in [q for q in self.order if q < len(fuse)]:
+            with torch.cuda.stream(self._stream(i)):
+                self._need(xs[i], i)
+                tl = [terms[i][j] for j in sorted(terms[i])]
+                for _, _, base in tl:
+                    self._need(base, i)
+                out[i] = self.upsample_add(xs[i], [t for t, _, _ in tl], [sh for _, sh, _ in tl], relu=True) if tl else torch.relu(xs[i])
+                self._mark(out[i], i)
+        return out
+
     def _hr_module(self, mod, xs):
         """xs[b]: tensor, or ('lazy', transition op, source tensor) for a branch this stage creates."""
+        if self.dag and not self.group_fuse:
+            return self._hr_module_dag(mod, xs)
         xs = list(xs)
         fuse = mod['fuse']
         terms = [dict() for _ in fuse]
@@ -669,6 +783,7 @@ class HipHRNet(ConvEngine):
     def features(self, x8):
         """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
         self._keep = []
+        self._evt = {}
         return self._features(x8)
 
     fuse_tail = True            # layer1: conv3 + residual + next conv1 of every Bottleneck in one launch (csrc/pam_pw.hip)
@@ -704,19 +819,24 @@ class HipHRNet(ConvEngine):
                 x = self.conv(b['c3'], y, res=r, relu=True)
         if self.stop_after == 'layer1':
             return x
-        self._barrier()                                               # branch streams must see layer1's output
+        dag = self.dag and not self.group_fuse
+        self._barrier()                                               # fork: branch streams must see layer1's output
+        if dag:
+            self._mark(x, 0)
         xs = [('lazy', self.t1[0], x), ('lazy', self.t1[1], x)]
         for m in self.stage2:
             xs = self._hr_module(m, xs)
         if self.stop_after == 'stage2':
             return self._end(xs)
-        self._barrier()                                               # the new branch's stream reads the last sum of stage 2
+        if not dag:
+            self._barrier()                                           # the new branch's stream reads the last sum of stage 2
         xs = xs + [('lazy', self.t2, xs[-1])]
         for m in self.stage3:
             xs = self._hr_module(m, xs)
         if self.stop_after == 'stage3':
             return self._end(xs)
-        self._barrier()
+        if not dag:
+            self._barrier()
         xs = xs + [('lazy', self.t3, xs[-1])]
         for m in self.stage4:
             xs = self._hr_module(m, xs)
