@@ -273,6 +273,29 @@ int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const void* x0, 
                                   const float* bias3, const void* w1_img, const float* bias1, void* out_x, void* out_y1,
                                   long long n_pixels, int tile_cfg);
 
+/* ---- launch plans: the conv stack's forward as a recorded DAG of launches, replayed from C (csrc/pam_plan.hip) -------------------
+ * Between pam_plan_begin() and pam_plan_end() the calling thread's convolution entry points (pam_conv2d_*, pam_basic_block_*,
+ * pam_upsample_add_*, pam_bottleneck_tail_*) RECORD their kernel launches instead of issuing them: function, geometry and a copy of the
+ * argument struct (device pointers baked in: the caller keeps those buffers alive and in place), on the logical stream chosen by
+ * pam_plan_stream (0 = the stream given to pam_plan_replay, 1..7 = side streams the plan owns).  pam_plan_record marks the current
+ * position of the current logical stream and returns an event id (>= 0); pam_plan_wait makes the current logical stream wait for such
+ * an event -- the dependency-precise schedule of pam/hrnet_hip.py (a consumer waits for exactly the tensors it reads).
+ * pam_plan_replay(plan, stream, mode): mode 0 issues the plan on real streams with real events in recorded order (side streams forked
+ * from `stream` at the start and joined into it at the end); mode 1 builds one explicit hipGraph from the plan (hipGraphAddKernelNode
+ * with the recorded dependencies) on first use and launches it.  Replaces the hipGraph capture of the forward: capturing streams that
+ * wait on each other's events in both directions segfaults in hipStreamEndCapture on ROCm 7.2.  pam_plan_info: {launches, events,
+ * logical streams, operations}. */
+int pam_plan_begin(void);
+int pam_plan_stream(int logical_stream);
+int pam_plan_record(void);
+int pam_plan_wait(int event_id);
+int pam_plan_end(void** plan);
+int pam_plan_abort(void);
+int pam_plan_info(const void* plan, int32_t* out4);
+int pam_plan_replay(void* plan, void* stream, int mode);
+int pam_plan_destroy(void* plan);
+const char* pam_plan_last_error(const void* plan);
+
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before
  * the cross-view match every rank contributes its views' keypoint records and receives everyone's: ONE all-gather per frame, enqueued on

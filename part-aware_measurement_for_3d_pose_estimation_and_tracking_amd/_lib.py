@@ -99,6 +99,16 @@ _SIGS = {
     'pam_basic_block_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_basic_block_nhwc_bf16_ex': (_I, [_P, _I, _P, _I]),
     'pam_bottleneck_tail_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I]),
+    'pam_plan_begin': (_I, []),
+    'pam_plan_stream': (_I, [_I]),
+    'pam_plan_record': (_I, []),
+    'pam_plan_wait': (_I, [_I]),
+    'pam_plan_end': (_I, [C.POINTER(_P)]),
+    'pam_plan_abort': (_I, []),
+    'pam_plan_info': (_I, [_P, _P]),
+    'pam_plan_replay': (_I, [_P, _P, _I]),
+    'pam_plan_destroy': (_I, [_P]),
+    'pam_plan_last_error': (C.c_char_p, [_P]),
     'pam_comm_unique_id': (_I, [_P]),
     'pam_comm_init': (_I, [C.POINTER(_P), _I, _I, _P, _I]),
     'pam_comm_destroy': (_I, [_P]),

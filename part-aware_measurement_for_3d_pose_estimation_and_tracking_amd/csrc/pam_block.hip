@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include <type_traits>
 #include "../../include/pam.h"
+#include "pam_launch.hpp"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -468,8 +469,8 @@ extern "C" int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const 
         (void)hipFuncSetAttribute((const void*)k_bblock<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (waves == 4) hipLaunchKernelGGL(k_bblock<4>, dim3(items), dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_bblock<8>, dim3(items), dim3(512), lds, (hipStream_t)stream, a);
+    if (waves == 4) pam_launch(k_bblock<4>, dim3(items), dim3(256), lds, (hipStream_t)stream, a);
+    else pam_launch(k_bblock<8>, dim3(items), dim3(512), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 

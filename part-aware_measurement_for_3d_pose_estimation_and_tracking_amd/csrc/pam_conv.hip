@@ -12,6 +12,7 @@
 #include <type_traits>
 #include <utility>
 #include "../../include/pam.h"
+#include "pam_launch.hpp"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;     // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -307,13 +308,13 @@ static int launch_conv(hipStream_t s, const ConvArgs& a) {
     if (a.relu > 1) {                                   // Darknet activation codes: the general-epilogue instantiation
         dim3 grid((a.M + BM_ - 1) / BM_, a.Cout / BN_);
         const size_t lds = (a.Kpad > KC ? 2 : 1) * (size_t)(BM_ + BN_) * ROWB;
-        hipLaunchKernelGGL((k_conv_igemm<NTW, WM, WN, true>), grid, dim3(64 * WM * WN), lds, s, a);
+        pam_launch(k_conv_igemm<NTW, WM, WN, true>, grid, dim3(64 * WM * WN), lds, s, a);
         return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
     }
     constexpr int BM = 64 * WM, BN = 16 * NTW * WN;
     dim3 grid((a.M + BM - 1) / BM, a.Cout / BN);
     const size_t lds = (a.Kpad > KC ? 2 : 1) * (size_t)(BM + BN) * ROWB;
-    hipLaunchKernelGGL((k_conv_igemm<NTW, WM, WN, false>), grid, dim3(64 * WM * WN), lds, s, a);
+    pam_launch(k_conv_igemm<NTW, WM, WN, false>, grid, dim3(64 * WM * WN), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
@@ -663,7 +664,7 @@ static int launch_c3_one(hipStream_t s, const C3Args& a) {
         if (slots > few) slots = few / 8 * 8;
         if (slots >= 8 && (int)grid.x > slots) grid.x = slots;
     }
-    hipLaunchKernelGGL((k_conv3x3<CIN, NTW, MT, NWAVES, PMAX>), grid, dim3(64 * NWAVES), lds, s, a);
+    pam_launch(k_conv3x3<CIN, NTW, MT, NWAVES, PMAX>, grid, dim3(64 * NWAVES), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 // cfg = MT * 10 + NWAVES  (MT = 4; NWAVES in {2, 3, 4}); the patch bound PMAX is picked from the actual tile
@@ -962,7 +963,7 @@ static int launch_c3s_one(hipStream_t s, const C3Args& a) {
         if (hipFuncSetAttribute((const void*)k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>), dim3(a.tiles_y * a.N, a.Cout / (16 * NTW)), dim3(512), lds, s, a);
+    pam_launch(k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>, dim3(a.tiles_y * a.N, a.Cout / (16 * NTW)), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, int pmax) {
@@ -1216,7 +1217,7 @@ static int launch_conv_gs(hipStream_t s, const ConvArgs& a) {
         attr = true;
     }
     const int ntile = ((a.M + 255) / 256) * (a.Cout / (16 * NTW));
-    hipLaunchKernelGGL((k_conv_gs<NTW, NBUF>), dim3(ntile < 256 ? ntile : 256), dim3(512), lds, s, a);
+    pam_launch(k_conv_gs<NTW, NBUF>, dim3(ntile < 256 ? ntile : 256), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
@@ -1329,10 +1330,10 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         const dim3 grid((N * a.Ho + 3) / 4), blk(256);
         hipStream_t s = (hipStream_t)stream;
         CONV_KIND(PAM_CONV_KERNEL_STEM);
-        if (stride == 2 && Cout == 64) hipLaunchKernelGGL((k_conv_stem<2, 4>), grid, blk, 0, s, t);
-        else if (stride == 2) hipLaunchKernelGGL((k_conv_stem<2, 2>), grid, blk, 0, s, t);
-        else if (Cout == 64) hipLaunchKernelGGL((k_conv_stem<1, 4>), grid, blk, 0, s, t);
-        else hipLaunchKernelGGL((k_conv_stem<1, 2>), grid, blk, 0, s, t);
+        if (stride == 2 && Cout == 64) pam_launch(k_conv_stem<2, 4>, grid, blk, 0, s, t);
+        else if (stride == 2) pam_launch(k_conv_stem<2, 2>, grid, blk, 0, s, t);
+        else if (Cout == 64) pam_launch(k_conv_stem<1, 4>, grid, blk, 0, s, t);
+        else pam_launch(k_conv_stem<1, 2>, grid, blk, 0, s, t);
         return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
     }
     if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && tile_cfg == -1) {
@@ -1468,7 +1469,7 @@ extern "C" int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int
     const size_t total = (size_t)N * H * W * (C / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_upsample_add, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    pam_launch(k_upsample_add, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
@@ -1496,7 +1497,7 @@ extern "C" int pam_conv2d_group_nhwc_bf16(void* stream, int n, const PamConvDesc
     for (int k = n; k < PAM_CONV_GROUP_MAX; ++k) { g.c[k] = g.c[0]; g.first[k] = blocks; }
     g.first[PAM_CONV_GROUP_MAX] = blocks;
     const size_t lds = 2 * (size_t)(64 + 48) * ROWB;          // members may differ in K: always both buffers
-    hipLaunchKernelGGL(k_conv_igemm_group, dim3(blocks), dim3(64), lds, (hipStream_t)stream, g);
+    pam_launch(k_conv_igemm_group, dim3(blocks), dim3(64), lds, (hipStream_t)stream, g);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
@@ -1570,6 +1571,6 @@ extern "C" int pam_upsample_add_group_nhwc_bf16(void* stream, int n, const PamUp
     }
     for (int k = n; k < PAM_UP_GROUP_MAX; ++k) { g.u[k] = g.u[0]; g.first[k] = blocks; }
     g.first[PAM_UP_GROUP_MAX] = blocks;
-    hipLaunchKernelGGL(k_upsample_add_group, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+    pam_launch(k_upsample_add_group, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

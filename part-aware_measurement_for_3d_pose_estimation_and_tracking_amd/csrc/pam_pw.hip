@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/pam.h"
+#include "pam_launch.hpp"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -231,7 +232,7 @@ static int launch_pw2(hipStream_t s, const PwArgs& a, int max_wg) {
     const int nwt = (a.M + 16 * MT - 1) / (16 * MT);
     int grid = (nwt + NW - 1) / NW;
     if (grid > max_wg) grid = max_wg;                   // persistent: one workgroup per CU, every wave walks wave tiles wt, wt + NW grid, ...
-    hipLaunchKernelGGL((k_pw2<S, RES, HAS2, MT, NW>), dim3(grid), dim3(64 * NW), lds, s, a);
+    pam_launch(k_pw2<S, RES, HAS2, MT, NW>, dim3(grid), dim3(64 * NW), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 

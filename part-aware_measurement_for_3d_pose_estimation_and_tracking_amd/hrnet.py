@@ -319,11 +319,39 @@ class HRNetPose(object):
         never written)."""
         return self._run(x, 'features')
 
+    plan_mode = int(os.environ.get('PAM_PLAN_MODE', '0'))      # 0: plans replay eagerly on real streams / events; 1: as one explicit hipGraph
+
+    def _head(self, f):
+        n, c, h, w = f.shape
+        hm = torch.empty((n, self.head_w.shape[0], h, w), dtype=torch.float32, device=f.device, memory_format=torch.channels_last)
+        rc = self.lib.pam_head_heatmaps(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), n * h * w,
+                                        C.c_void_p(f.data_ptr()), c, C.c_void_p(self.head_w.data_ptr()),
+                                        C.c_void_p(self.head_b.data_ptr()), self.head_w.shape[0], C.c_void_p(hm.data_ptr()))
+        if rc != 0:
+            raise _lib.PamError('pam_head_heatmaps failed: %d' % rc)
+        return hm
+
     def _run(self, x, kind):
         n = x.shape[0]
         if not self.use_graph:
             with torch.no_grad():
                 return self._forward(x, kind)
+        if self.backend == 'hip' and self.hip.dag:
+            # the product path: the conv stack as a LAUNCH PLAN (recorded once per crop count, replayed from C with the dependency-precise
+            # stream schedule; csrc/pam_plan.hip) -- the captured-hipGraph form of that schedule crashes the ROCm 7.2 capture
+            g = self._graphs.get((n, 'features'))
+            if g is None:
+                static_in = torch.empty_like(x)
+                static_in.copy_(x)
+                with torch.no_grad():
+                    plan = self.hip.make_plan(static_in)
+                g = (plan, static_in, plan.out)
+                self._graphs[(n, 'features')] = g
+            plan, static_in, static_out = g
+            if static_in.data_ptr() != x.data_ptr():
+                static_in.copy_(x)
+            plan.replay(self.plan_mode)
+            return static_out if kind == 'features' else self._head(static_out)
         g = self._graphs.get((n, kind))
         if g is None:
             other = self._graphs.get((n, 'features' if kind == 'heatmaps' else 'heatmaps'))

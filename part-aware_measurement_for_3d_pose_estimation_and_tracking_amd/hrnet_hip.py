@@ -4,6 +4,7 @@ The folded (conv + bias) PyTorch module of hrnet.py is walked once into packed w
 ``pam_conv2d_nhwc_bf16`` per convolution -- bias, residual add and ReLU fused into its epilogue -- plus one
 ``pam_upsample_add_nhwc_bf16`` per fuse-layer output that has coarser inputs.  Activations are NHWC bf16 torch tensors
 (channels-last); torch is used for memory and the stream only.  The whole forward is hipGraph-capturable."""
+import contextlib
 import ctypes as C
 
 import torch
@@ -172,6 +173,30 @@ class PackedTail(object):
                 im1[sl] = torch.gather(w, 1, cin.reshape(64, 64)).reshape(64, 8, 8)
             self.w1 = im1.to(torch.bfloat16).to(device).contiguous()
             self.b1 = zb(conv1_next).to(device).contiguous()
+
+
+class LaunchPlan(object):
+    """A recorded forward (pam_plan_*): ``replay`` issues it on the current stream (+ the plan's side streams); ``out`` is the static
+    output tensor.  Holds every tensor of the recorded forward alive: the launches carry their addresses."""
+
+    def __init__(self, lib, handle, keep, out, device):
+        self.lib, self.handle, self.keep, self.out, self.device = lib, handle, keep, out, device
+        info = (C.c_int32 * 4)()
+        lib.pam_plan_info(handle, info)
+        self.launches, self.events, self.streams, self.ops = [int(v) for v in info]
+
+    def replay(self, mode=0):
+        rc = self.lib.pam_plan_replay(self.handle, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), mode)
+        if rc != 0:
+            raise _lib.PamError('pam_plan_replay failed (%d): %s' % (rc, self.lib.pam_plan_last_error(self.handle).decode()))
+        return self.out
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.pam_plan_destroy(self.handle); self.handle = None
+        except Exception:
+            pass
 
 
 class ConvEngine(object):
@@ -510,6 +535,8 @@ class HipHRNet(ConvEngine):
 
     def _barrier(self):
         """Join and re-fork all branch streams through the caller's stream."""
+        if self.plan_rec:
+            return                                      # a plan forks its side streams at the start of a replay and joins them at the end
         if self.multi_stream:
             cur = torch.cuda.current_stream(self.device)
             for st in self.side:
@@ -524,13 +551,59 @@ class HipHRNet(ConvEngine):
     # waits are plain edges.  (All side streams are forked from the caller's stream at the start of the forward and joined at its end.)
     dag = True
 
+    plan_rec = False            # True while a launch plan is being recorded (make_plan): stream switches, event records and waits go to
+                                # pam_plan_* instead of torch streams / events, launches are stored by the library instead of issued
+
+    @contextlib.contextmanager
+    def _on(self, b):
+        """Everything issued inside runs on branch stream b."""
+        if self.plan_rec:
+            prev, lane = self._plan_cur, (self.lane_of[b] if self.multi_stream else 0)
+            self.lib.pam_plan_stream(lane); self._plan_cur = lane
+            try:
+                yield
+            finally:
+                self.lib.pam_plan_stream(prev); self._plan_cur = prev
+        else:
+            with torch.cuda.stream(self._stream(b)):
+                yield
+
+    def make_plan(self, x8):
+        """Record the forward on x8 (a static input buffer) as a launch plan (csrc/pam_plan.hip) -> LaunchPlan; its ``out`` is the
+        static output tensor every replay fills."""
+        assert self.dag and not self.group_fuse and self.prof is None
+        rc = self.lib.pam_plan_begin()
+        if rc != 0:
+            raise _lib.PamError('pam_plan_begin failed (%d)' % rc)
+        self.plan_rec, self._plan_cur = True, 0
+        try:
+            self._keep, self._evt = [], {}
+            out = self._features(x8)
+        except Exception:
+            self.lib.pam_plan_abort()
+            raise
+        finally:
+            self.plan_rec = False
+        h = C.c_void_p()
+        rc = self.lib.pam_plan_end(C.byref(h))
+        if rc != 0:
+            raise _lib.PamError('pam_plan_end failed (%d)' % rc)
+        keep, self._keep = self._keep + [x8], []
+        return LaunchPlan(self.lib, h, keep, out, self.device)
+
     def _sobj(self, b):
         l = self.lane_of[b]
         return torch.cuda.current_stream(self.device) if (l == 0 or not self.multi_stream) else self.side[l - 1]
 
     def _mark(self, t, b):
         """t was just produced on branch stream b."""
-        if self.multi_stream:
+        if self.plan_rec:
+            if self.multi_stream:
+                prev, lane = self._plan_cur, self.lane_of[b]
+                self.lib.pam_plan_stream(lane)
+                self._evt[id(t)] = (self.lib.pam_plan_record(), lane, t)
+                self.lib.pam_plan_stream(prev)
+        elif self.multi_stream:
             ev = torch.cuda.Event()
             ev.record(self._sobj(b))
             self._evt[id(t)] = (ev, self.lane_of[b], t)       # the tensor is kept so that its id cannot be reused within the forward
@@ -540,7 +613,11 @@ class HipHRNet(ConvEngine):
         if self.multi_stream:
             e = self._evt.get(id(t))
             if e is not None and e[1] != self.lane_of[b]:
-                self._sobj(b).wait_event(e[0])
+                if self.plan_rec:
+                    prev = self._plan_cur
+                    self.lib.pam_plan_stream(self.lane_of[b]); self.lib.pam_plan_wait(e[0]); self.lib.pam_plan_stream(prev)
+                else:
+                    self._sobj(b).wait_event(e[0])
 
     def _hr_module_dag(self, mod, xs):
         xs = list(xs)
@@ -561,7 +638,7 @@ class HipHRNet(ConvEngine):
 
         def transition(b):
             if isinstance(xs[b], tuple):                  # a branch this stage creates: its transition conv runs on its own stream
-                with torch.cuda.stream(self._stream(b)):
+                with self._on(b):
                     self._need(xs[b][2], b)
                     xs[b] = self.conv(xs[b][1], xs[b][2], relu=True)
                     self._mark(xs[b], b)
@@ -579,7 +656,7 @@ class HipHRNet(ConvEngine):
         for b in [q for q in self.order if q < nb]:
             blocks = mod['branches'][b] if b not in grouped else []
             transition(b)
-            with torch.cuda.stream(self._stream(b)):
+            with self._on(b):
                 x = xs[b]
                 self._need(x, b)
                 for c1, c2 in blocks:
@@ -620,7 +697,7 @@ class HipHRNet(ConvEngine):
         # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order, on stream i
         out = [None] * len(fuse)
         for i in [q for q in self.order if q < len(fuse)]:
-            with torch.cuda.stream(self._stream(i)):
+            with self._on(i):
                 self._need(xs[i], i)
                 tl = [terms[i][j] for j in sorted(terms[i])]
                 for _, _, base in tl:
@@ -791,7 +868,7 @@ class HipHRNet(ConvEngine):
     stop_after = None           # diagnostics (tools/stage_times.py): 'stem' | 'layer1' | 'stage2' | 'stage3' -> the forward ends there
 
     def _end(self, xs):
-        if self.multi_stream:                                         # final join only (no re-fork: capture must end with no forked stream)
+        if self.multi_stream and not self.plan_rec:                                         # final join only (no re-fork: capture must end with no forked stream)
             cur = torch.cuda.current_stream(self.device)
             for st in self.side:
                 cur.wait_stream(st)

@@ -9,7 +9,7 @@ from pam import hrnet
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, default=20); ap.add_argument('--iters', type=int, default=30)
-ap.add_argument('--fuse-max', type=int, default=0); ap.add_argument('--no-branch-streams', action='store_true')
+ap.add_argument('--fuse-max', type=int, default=0); ap.add_argument('--mode', type=int, default=0); ap.add_argument('--no-branch-streams', action='store_true')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 net = hrnet.HRNetPose(48, 17, None, use_graph=False, backend='hip')
@@ -22,17 +22,13 @@ for stop in ('stem', 'layer1', 'stage2', 'stage3', None):
     hip.stop_after = stop
     hip.prof = None
     hip.features(x); torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream(dev)
-    with torch.cuda.stream(s):
-        with torch.cuda.graph(g, stream=s):
-            y = hip.features(x)
-    for _ in range(3): g.replay()
+    plan = hip.make_plan(x)                          # the product's replay form: a launch plan (dependency-precise schedule)
+    for _ in range(3): plan.replay(args.mode)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
     e0.record()
-    for _ in range(args.iters): g.replay()
+    for _ in range(args.iters): plan.replay(args.mode)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / args.iters
-    print('%-8s prefix %.3f ms   (+%.3f)' % (stop or 'all', ms, ms - prev), flush=True)
+    print('%-8s prefix %.3f ms   (+%.3f)   %d launches, %d events' % (stop or 'all', ms, ms - prev, plan.launches, plan.events), flush=True)
     prev = ms
