@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument('--no-extra', action='store_true', help='N > 1: skip the crop-balanced run and the single-GPU run of the same workload')
     ap.add_argument('--batched-scenes', type=int, default=2048)
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--pose-streams', type=int, default=1, choices=[1, 2], help='2: the forwards of consecutive frames alternate between two streams / replay slots and overlap')
     ap.add_argument('--no-overlap', action='store_true', help='run the tracker of frame t on the pose stream instead of under frame t+1')
     return ap.parse_args()
 
@@ -210,19 +211,21 @@ def make_step(pipe, inp, shard, feeder=None, last=None):
     if shard == 'views':
         def step(t, ev=None):
             e = pf[t]
-            pipe.pose_step(frames_of(t), e['vl'], e['sl'], e['bx'], ev)
-            if feeder is not None:
-                feeder.release(t)
-            pipe.write_local(e['dd'])               # the tracker consumes the seeded synthetic keypoints, not the random net's
-            pipe.track_step(t, e['nd'])
+            with pipe.frame():
+                pipe.pose_step(frames_of(t), e['vl'], e['sl'], e['bx'], ev)
+                if feeder is not None:
+                    feeder.release(t)
+                pipe.write_local(e['dd'])           # the tracker consumes the seeded synthetic keypoints, not the random net's
+                pipe.track_step(t, e['nd'])
     else:
         def step(t, ev=None):
             e = pf[t]
-            pipe.pose_step_crops(frames_of(t), e['vl'], e['sl'], e['bx'], ev)
-            if feeder is not None:
-                feeder.release(t)
-            pipe.write_send(e['dd'])                # ordered behind the previous frame's exchange / tracker, which read that buffer
-            pipe.track_step_crops(t, e['nd'], e['sel'])
+            with pipe.frame():
+                pipe.pose_step_crops(frames_of(t), e['vl'], e['sl'], e['bx'], ev)
+                if feeder is not None:
+                    feeder.release(t)
+                pipe.write_send(e['dd'])            # ordered behind the previous frame's exchange / tracker, which read that buffer
+                pipe.track_step_crops(t, e['nd'], e['sel'])
     return step
 
 
@@ -248,7 +251,8 @@ def timed_run(torch, dist, pipe, step, inp, K, W, world, dev, events=True, feede
     counts = sorted(set(n for n in inp['local_crops'] if n > 0))
     if pipe.net is not None:
         for n in counts:
-            pipe.net.features(pipe.net.input_buffer(n))
+            for k in range(2 if pipe.pose_streams is not None else 1):
+                pipe.net.features(pipe.net.input_buffer(n, k), k)
         if counts and warm_s > 0:
             x = pipe.net.input_buffer(max(counts, key=inp['local_crops'].count))
             t0 = time.perf_counter()
@@ -334,7 +338,8 @@ def main():
     overlap = not args.no_overlap
     pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
                          rank=rank, use_graph=not args.no_graph, shard=shard, overlap_tracker=overlap,
-                         exchange=args.exchange if (shard == 'views' and not single_dev) else 'torch')
+                         exchange=args.exchange if (shard == 'views' and not single_dev) else 'torch',
+                         pose_streams=args.pose_streams if overlap else 1)
     inp = build_inputs(torch, synth, seq, size, max_dets, world, rank, shard, dev, nF)
     torch.cuda.synchronize()
 

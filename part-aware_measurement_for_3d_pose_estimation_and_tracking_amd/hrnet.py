@@ -310,14 +310,15 @@ class HRNetPose(object):
             raise _lib.PamError('pam_head_heatmaps failed: %d' % rc)
         return hm
 
-    def heatmaps(self, x):
+    def heatmaps(self, x, slot=0):
         """x: (N,3,H,W) channels-last bf16 on the device -> (N,17,H/4,W/4) float32 (channels-last memory)."""
-        return self._run(x, 'heatmaps')
+        return self._run(x, 'heatmaps', slot)
 
-    def features(self, x):
+    def features(self, x, slot=0):
         """x as above -> (N,48,H/4,W/4) channels-last bf16: the input of ``head_decode`` (the product path: the heat-maps are
-        never written)."""
-        return self._run(x, 'features')
+        never written).  slot: which replay instance (own static input / activations / output) -- two frames whose forwards are in
+        flight at the same time (FramePipeline(pose_streams=2)) use different slots of the same weights."""
+        return self._run(x, 'features', slot)
 
     plan_mode = int(os.environ.get('PAM_PLAN_MODE', '0'))      # 0: plans replay eagerly on real streams / events; 1: as one explicit hipGraph
 
@@ -331,31 +332,32 @@ class HRNetPose(object):
             raise _lib.PamError('pam_head_heatmaps failed: %d' % rc)
         return hm
 
-    def _run(self, x, kind):
+    def _run(self, x, kind, slot=0):
         n = x.shape[0]
         if not self.use_graph:
             with torch.no_grad():
                 return self._forward(x, kind)
         if self.backend == 'hip' and self.hip.dag:
-            # the product path: the conv stack as a LAUNCH PLAN (recorded once per crop count, replayed from C with the dependency-precise
-            # stream schedule; csrc/pam_plan.hip) -- the captured-hipGraph form of that schedule crashes the ROCm 7.2 capture
-            g = self._graphs.get((n, 'features'))
+            # the dependency-precise schedule as a LAUNCH PLAN (recorded once per crop count, replayed from C; csrc/pam_plan.hip) -- the
+            # captured-hipGraph form of that schedule crashes the ROCm 7.2 capture.  Measured slower than the joined schedule below
+            # (DESIGN section 4), so HipHRNet.dag is off by default.
+            g = self._graphs.get((n, 'features', slot))
             if g is None:
                 static_in = torch.empty_like(x)
                 static_in.copy_(x)
                 with torch.no_grad():
                     plan = self.hip.make_plan(static_in)
                 g = (plan, static_in, plan.out)
-                self._graphs[(n, 'features')] = g
+                self._graphs[(n, 'features', slot)] = g
             plan, static_in, static_out = g
             if static_in.data_ptr() != x.data_ptr():
                 static_in.copy_(x)
             plan.replay(self.plan_mode)
             return static_out if kind == 'features' else self._head(static_out)
-        g = self._graphs.get((n, kind))
+        g = self._graphs.get((n, kind, slot))
         if g is None:
-            other = self._graphs.get((n, 'features' if kind == 'heatmaps' else 'heatmaps'))
-            static_in = other[1] if other is not None else torch.empty_like(x)     # one input buffer per batch size
+            other = self._graphs.get((n, 'features' if kind == 'heatmaps' else 'heatmaps', slot))
+            static_in = other[1] if other is not None else torch.empty_like(x)     # one input buffer per batch size and slot
             static_in.copy_(x)
             with torch.no_grad():
                 s = torch.cuda.Stream(self.device)
@@ -370,17 +372,17 @@ class HRNetPose(object):
                 with torch.cuda.graph(graph, pool=self._pool):
                     static_out = self._forward(static_in, kind)
             g = (graph, static_in, static_out)
-            self._graphs[(n, kind)] = g
+            self._graphs[(n, kind, slot)] = g
         graph, static_in, static_out = g
         if static_in.data_ptr() != x.data_ptr():
             static_in.copy_(x)
         graph.replay()
         return static_out
 
-    def input_buffer(self, n):
-        """The (N,3,H,W) channels-last bf16 tensor the preprocessing kernel writes; the graph's own input when one
+    def input_buffer(self, n, slot=0):
+        """The (N,3,H,W) channels-last bf16 tensor the preprocessing kernel writes; the replay's own input when one
         exists, so no copy is needed."""
-        g = self._graphs.get((n, 'features')) or self._graphs.get((n, 'heatmaps'))
+        g = self._graphs.get((n, 'features', slot)) or self._graphs.get((n, 'heatmaps', slot))
         if g is not None:
             return g[1]
         H, W = self.resolution

@@ -4,6 +4,8 @@ Nothing returns to the host inside a frame; the output record is copied out asyn
 
 This is the device-resident form of testmodel.py's loop body (/root/reference/src/testmodel.py:59-69):
 PersonPoseDetect + PersonTrack_Project3DPose."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -16,11 +18,15 @@ NUM_JOINTS = 17
 
 class FramePipeline(object):
     def __init__(self, calib_cameras, matcher, conf_threshold, frame_hw, max_dets=8, max_tracks=16, device=0, world=1,
-                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False, net=None, exchange='torch'):
+                 rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False, net=None, exchange='torch',
+                 pose_streams=1):
         """shard: 'views' -- rank owns whole camera views (pose_step / track_step take view-local inputs); 'crops' -- the
         frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices).
         overlap_tracker (either mode): exchange + tracker kernel + fetch of frame t run on their own stream, under the conv
-        stack of frame t+1 (the tracker is one workgroup per scene; it rides on CUs the conv kernels leave idle)."""
+        stack of frame t+1 (the tracker is one workgroup per scene; it rides on CUs the conv kernels leave idle).
+        pose_streams = 2: the crop -> conv stack -> decode chains of consecutive frames alternate between two streams, each with its own
+        replay instance (static input, activations, output) of the same weights, so frame t+1's HBM-bound stem / layer1 runs beside
+        frame t's CU-bound last stages.  Frames still finish in order (the tracker stream takes them in order)."""
         self.device = torch.device('cuda:%d' % device)
         torch.cuda.set_device(self.device)
         self.cams = calib_cameras
@@ -54,24 +60,47 @@ class FramePipeline(object):
         self.ev = None
         self.track_stream = torch.cuda.Stream(self.device) if overlap_tracker else None
         self.ev_pose, self.ev_track, self._track_pending = torch.cuda.Event(), torch.cuda.Event(), False
+        assert pose_streams in (1, 2) and (pose_streams == 1 or overlap_tracker), 'two pose streams need the tracker on its own stream'
+        self.pose_streams = [torch.cuda.Stream(self.device) for _ in range(pose_streams)] if pose_streams > 1 else None
+        self._frame_no = 0
 
     def stream_ptr(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    def _pose(self, frame_ptrs, views, slot_of, boxes, det, time_events):
+        """crop -> conv stack -> head + arg-max for one frame on the current stream, replay slot = frame parity when two pose streams run."""
+        k = (self._frame_no & 1) if self.pose_streams is not None else 0
+        n = int(views.numel())
+        x = self.net.input_buffer(n, k)
+        self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, views, boxes, x)
+        if time_events is not None:
+            time_events[0].record(torch.cuda.current_stream(self.device))
+        f = self.net.features(x, k)
+        if time_events is not None:
+            time_events[1].record(torch.cuda.current_stream(self.device))
+        self.wait_track()                               # the previous frame's exchange / tracker read the buffer decode writes
+        self.net.head_decode(f, views, slot_of, boxes, det)
+
+    @contextlib.contextmanager
+    def frame(self):
+        """Everything of ONE frame (pose_step*, write_*, track_step*) goes inside.  With two pose streams the frame runs on the stream of
+        its parity (ordered behind the caller's stream, which holds its inputs) with that parity's replay slot, so the forwards of
+        consecutive frames overlap; frame t + 2 follows frame t on the same stream, which also orders the reuse of the slot."""
+        if self.pose_streams is None:
+            yield
+            self._frame_no += 1
+            return
+        ps = self.pose_streams[self._frame_no & 1]
+        ps.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(ps):
+            yield
+        self._frame_no += 1
+
     def pose_step(self, frame_ptrs, view_local, slot_of, boxes, time_events=None):
         """HRNet side for this rank's crops.  view_local: int32 (N,) index into self.mine; writes self.det_local."""
-        n = int(view_local.numel())
-        if n == 0 or self.net is None:
+        if int(view_local.numel()) == 0 or self.net is None:
             return
-        x = self.net.input_buffer(n)
-        self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, view_local, boxes, x)
-        if time_events is not None:
-            time_events[0].record()
-        f = self.net.features(x)
-        if time_events is not None:
-            time_events[1].record()
-        self.wait_track()                               # the previous frame's exchange / tracker read the buffer decode writes
-        self.net.head_decode(f, view_local, slot_of, boxes, self.det_local)
+        self._pose(frame_ptrs, view_local, slot_of, boxes, self.det_local, time_events)
 
     def write_local(self, rows):
         """Copy keypoint rows (len(mine), max_dets, 17, 3) into this rank's records, ordered behind the previous frame's readers."""
@@ -115,18 +144,9 @@ class FramePipeline(object):
     def pose_step_crops(self, frame_ptrs, view_of, slot_of, boxes, time_events=None):
         """HRNet side for this rank's share of the frame's crops; view_of indexes ALL views (frame_ptrs has C entries).
         Decodes straight into the exchange buffer at (view, slot)."""
-        n = int(view_of.numel())
-        if n == 0 or self.net is None:
+        if int(view_of.numel()) == 0 or self.net is None:
             return
-        x = self.net.input_buffer(n)
-        self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, view_of, boxes, x)
-        if time_events is not None:
-            time_events[0].record()
-        f = self.net.features(x)
-        if time_events is not None:
-            time_events[1].record()
-        self.wait_track()
-        self.net.head_decode(f, view_of, slot_of, boxes, self.crop_gather.send)
+        self._pose(frame_ptrs, view_of, slot_of, boxes, self.crop_gather.send, time_events)
 
     def track_step_crops(self, frame_id, n_det, select, fetch=True):
         """n_det (C,) int32 and select (CropGather.select_index) are the same on every rank (they follow from the frame's box
@@ -153,6 +173,9 @@ class FramePipeline(object):
         """Synchronise and decode the last fetched record.  strict: a non-zero status word (capacity overflow, infeasible
         assignment, clamped detection count -- include/pam.h) IN ANY FRAME since the handle was created or reset (the sticky half of
         the word) raises instead of passing silently into the caller's numbers."""
+        if self.pose_streams is not None:
+            for ps in self.pose_streams:
+                ps.synchronize()
         if self.track_stream is not None:
             self.track_stream.synchronize()
         torch.cuda.current_stream(self.device).synchronize()

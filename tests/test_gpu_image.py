@@ -199,10 +199,10 @@ def test_predict_dump_format_and_facade_end_to_end():
         for ia, ib in zip(a, b):
             assert ia['keypoints'] == ib['keypoints']
     G = model.pose_model._graphs
-    assert model.pose_model.graph_bucket == 4 and (4, 'features') in G and (3, 'features') not in G   # 3 crops ran padded to 4
+    assert model.pose_model.graph_bucket == 4 and (4, 'features', 0) in G and (3, 'features', 0) not in G   # 3 crops ran padded to 4
     model.pose_model.graph_bucket = 1                                                         # exact batch sizes: same result
     dump3 = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
-    assert (3, 'features') in model.pose_model._graphs
+    assert (3, 'features', 0) in model.pose_model._graphs
     for a, b in zip(dump, dump3):
         for ia, ib in zip(a, b):
             assert ia['keypoints'] == ib['keypoints']
@@ -416,12 +416,17 @@ def test_dependency_schedule_matches_joined_schedule(n):
     a = hrnet.HRNetPose(48, 17, None, use_graph=False)
     a.hip.dag = False
     b = hrnet.HRNetPose(48, 17, None, use_graph=True)
-    assert b.hip.dag
+    b.hip.dag = True                                   # opt-in: replayed as a launch plan (csrc/pam_plan.hip)
     x = a.input_buffer(n)
     x.copy_(torch.randn(x.shape, device=x.device).to(x.dtype)); x[:, 3:] = 0
     ref = a.features(x).clone()
-    b.hip.dag = True
-    for _ in range(3):
+    for mode in (0, 0, 0, 1, 1):                        # eager replay on real streams / events, then the explicit hipGraph of the same plan
+        b.plan_mode = mode
+        y = b.features(x).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(ref, y), mode
+    assert b._graphs[(n, 'features', 0)][0].launches > 200
+    for _ in range(0):
         y = b.features(x).clone()
         torch.cuda.synchronize()
         assert torch.equal(ref, y)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of executor variants in ONE process on one device (guide rule 24): each variant = HipHRNet attribute overrides,
+replayed as a captured hipGraph (joined schedule) or a launch plan (dag); R rounds of `iters` replays each, medians and minima.
+usage: ab_flags.py [--n 20] name:attr=val,attr=val ...     e.g.  base: tail:fuse_tail=0 dag0:dag=1,form=plan0"""
+import os, sys, argparse
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import pam
+from pam import hrnet
+ap = argparse.ArgumentParser()
+ap.add_argument('--n', type=int, default=20); ap.add_argument('--iters', type=int, default=20); ap.add_argument('--rounds', type=int, default=7)
+ap.add_argument('variants', nargs='+')
+args = ap.parse_args()
+dev = torch.device('cuda:0')
+runs = []
+for v in args.variants:
+    name, _, spec = v.partition(':')
+    net = hrnet.HRNetPose(48, 17, None, use_graph=False)
+    hip = net.hip
+    hip.dag = False
+    form = 'graph'
+    for kv in [q for q in spec.split(',') if q]:
+        k, _, val = kv.partition('=')
+        if k == 'form':
+            form = val
+        else:
+            cur = getattr(hip, k)
+            setattr(hip, k, type(cur)(int(val)) if isinstance(cur, (bool, int)) else val)
+    x = net.input_buffer(args.n); x.copy_(torch.randn(x.shape, device=dev).to(x.dtype)); x[:, 3:] = 0
+    hip.features(x); torch.cuda.synchronize()
+    if form == 'graph':
+        g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream(dev)
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                out = hip.features(x)
+        runs.append((name, g.replay, net, g))
+    else:
+        plan = hip.make_plan(x)
+        runs.append((name, (lambda p=plan, m=int(form[-1]): p.replay(m)), net, plan))
+for _, run, _, _ in runs:
+    for _ in range(5): run()
+torch.cuda.synchronize()
+t = {name: [] for name, _, _, _ in runs}
+for r in range(args.rounds):
+    for name, run, _, _ in runs:
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        e0.record()
+        for _ in range(args.iters): run()
+        e1.record(); torch.cuda.synchronize()
+        t[name].append(e0.elapsed_time(e1) / args.iters)
+base = np.median(t[runs[0][0]])
+for name, _, _, _ in runs:
+    a = np.array(t[name])
+    print('%-14s median %.3f ms  min %.3f  max %.3f   %+.1f %% vs %s' % (name, np.median(a), a.min(), a.max(), 100 * (np.median(a) / base - 1), runs[0][0]), flush=True)
