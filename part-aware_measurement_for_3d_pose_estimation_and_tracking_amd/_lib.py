@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libpam_hip.so')
+LIB_PATH = os.environ.get('PAM_LIB') or os.path.join(_HERE, 'csrc', 'libpam_hip.so')     # PAM_LIB: another build of the same library (tools/ab_build.sh)
 
 PAM_J = 17
 PAM_MAX_TAPS = 16

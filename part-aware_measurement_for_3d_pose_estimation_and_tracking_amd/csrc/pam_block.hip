@@ -307,12 +307,23 @@ __device__ __forceinline__ void bblock_item(const BBranch& a, int v, char* smem)
             const bool ok = p < n1 && col < a.W && (unsigned)iy < (unsigned)a.H;
             if (p > n1) continue;                                        // junk tiles past the last row: nothing reads them, and they may lie outside X
             char* d = Xb + (size_t)(p + 1) * PA + (48 * slab + 12 * g) * 2;
+            uint32_t ov[6];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                uint32_t lo = relu_bf16x2(pack_bf16x2(acc[i][j][0], acc[i][j][1])), hi = relu_bf16x2(pack_bf16x2(acc[i][j][2], acc[i][j][3]));
-                if (!ok) { lo = 0; hi = 0; }
-                *(u32x2*)(d + 8 * j) = (u32x2){lo, hi};
+                ov[2 * j] = ok ? relu_bf16x2(pack_bf16x2(acc[i][j][0], acc[i][j][1])) : 0u;
+                ov[2 * j + 1] = ok ? relu_bf16x2(pack_bf16x2(acc[i][j][2], acc[i][j][3])) : 0u;
             }
+            // 24 bytes at a 24-byte step: one 16-byte + one 8-byte write (16 + 8 for even g, 8 + 16 for odd g, as the epilogue's stores)
+            // instead of three 8-byte writes -- at a slot pitch of 96 B a ds_write_b64 of 16 consecutive slots is 4-way bank-conflicted
+            // (24.5 % of the kernel's LDS cycles were conflict cycles), the 8-lane groups of a ds_write_b128 only 2-way
+#ifdef PAM_BB_WRITE64                                                         // A/B hook (tools/ab_build.sh): the old three 8-byte writes
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *(u32x2*)(d + 8 * j) = (u32x2){ov[2 * j], ov[2 * j + 1]};
+#else
+            const bool odd = g & 1;
+            *(u32x4*)(d + (odd ? 8 : 0)) = odd ? (u32x4){ov[2], ov[3], ov[4], ov[5]} : (u32x4){ov[0], ov[1], ov[2], ov[3]};
+            *(u32x2*)(d + (odd ? 0 : 16)) = odd ? (u32x2){ov[0], ov[1]} : (u32x2){ov[4], ov[5]};
+#endif
         }
         if (tid < PA / 16) *(u32x4*)(Xb + tid * 16) = (u32x4){0, 0, 0, 0};      // slot 0 = the padding column left of the first row
     }

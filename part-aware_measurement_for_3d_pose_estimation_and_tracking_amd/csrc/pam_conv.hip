@@ -1005,7 +1005,7 @@ static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, 
 // fragment addresses are constants + immediates.  One s_barrier per chunk (loaders: chunk k has landed; multipliers: chunk k - 1 is
 // consumed), residual folded into the bias before the K loop, epilogue = convert + ReLU (channels >= relu_from) + 16-byte stores.
 // ====================================================================================================================
-template <int NTW, int NBUF>
+template <int NTW, int NBUF, bool RES>
 __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
     constexpr int BM = 256, BN = 16 * NTW, AIMG = BM * 128, BIMG = BN * 128, BUF = AIMG + BIMG;
     constexpr int APW = AIMG / 1024 / 4, BPIECES = BIMG / 1024, BPW = (BPIECES + 3) / 4, NPER = APW + BPW;
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
             c3_row_load<NTW>(rs_res, m < a.M ? (unsigned)(((size_t)m * a.Cout + n0 + g * 4 * NTW) * 2) : OOB_OFFSET, g, rres[i]);
         }
     };
-    if (a.res) res_load(0);
+    if (RES && a.res) res_load(0);
     // fragment addresses: row (lane & 15) of a 16-row window, k-group g of k-step ks -> piece (4 ks + g) ^ ((lane & 15) >> 1)
     const unsigned sw = (unsigned)((g ^ ((lane & 15) >> 1)) << 4);                       // ks = 0; ks = 1 is sw ^ 64
     const unsigned aoff0 = (unsigned)((wave * 64 + (lane & 15)) * 128) + sw;
@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     acc[i][j] = bias4[j];
-                    if (a.res) {
+                    if (RES && a.res) {
                         acc[i][j][0] += __builtin_bit_cast(float, rres[i][2 * j] << 16);
                         acc[i][j][1] += __builtin_bit_cast(float, rres[i][2 * j] & 0xffff0000u);
                         acc[i][j][2] += __builtin_bit_cast(float, rres[i][2 * j + 1] << 16);
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
                 __builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0): this wave is done reading chunk G
                 asm volatile("s_barrier" ::: "memory");                                   // chunk G + 1 has landed; chunk G's buffer is free
                 if (c + 1 < nchunks) ldfrag(G + 1, 0, af[0], bfr[0]);
-                else if (a.res) res_load(t + 1);                                         // next tile's residual: lands under the epilogue
+                else if (RES && a.res) res_load(t + 1);                                         // next tile's residual: lands under the epilogue
             }
             mfmas(af[1], bfr[1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -1207,18 +1207,23 @@ static bool conv_gs_auto(const ConvArgs& a) {
     const int rounds = (tiles + 255) / 256;
     return nslab == 1 || tiles <= 256 || tiles * 100 >= rounds * 256 * 78;
 }
-template <int NTW>
-static int launch_conv_gs(hipStream_t s, const ConvArgs& a) {
+template <int NTW, bool RES>
+static int launch_conv_gs_r(hipStream_t s, const ConvArgs& a) {
     constexpr int NBUF = 3;
     constexpr size_t lds = (size_t)NBUF * (256 + 16 * NTW) * 128;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_conv_gs<NTW, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
+        if (hipFuncSetAttribute((const void*)k_conv_gs<NTW, NBUF, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
         attr = true;
     }
     const int ntile = ((a.M + 255) / 256) * (a.Cout / (16 * NTW));
-    pam_launch(k_conv_gs<NTW, NBUF>, dim3(ntile < 256 ? ntile : 256), dim3(512), lds, s, a);
+    pam_launch(k_conv_gs<NTW, NBUF, RES>, dim3(ntile < 256 ? ntile : 256), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+template <int NTW>
+static int launch_conv_gs(hipStream_t s, const ConvArgs& a) {
+    if constexpr (NTW >= 6) return a.res ? PAM_E_ARG : launch_conv_gs_r<NTW, false>(s, a);   // the wide slab has no registers left for the residual rows
+    else return a.res ? launch_conv_gs_r<NTW, true>(s, a) : launch_conv_gs_r<NTW, false>(s, a);
 }
 
 // ====================================================================================================================
@@ -1408,7 +1413,9 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     if (tile_cfg >= 100) tile_cfg = -1;
     // streamed implicit GEMM (k_conv_gs): codes 0 / 1, taps in a 32-bit mask, whole 16-byte pieces per tap (Cin % 8 == 0)
     const bool gs_ok = relu <= 1 && KH * KW <= 9 && Cin % 8 == 0 && (size_t)N * H * W * in_cstride * 2 < (1u << 31);
-    if (tile_cfg == 8 && !gs_ok) return PAM_E_ARG;
+    if ((tile_cfg == 8 || tile_cfg == 9) && !gs_ok) return PAM_E_ARG;
+    if (tile_cfg == 9)                                  // streamed implicit GEMM with 96-channel slabs: the gathered pixel tile feeds twice the MFMAs
+        return Cout % 96 == 0 ? (CONV_KIND(PAM_CONV_KERNEL_GS), launch_conv_gs<6>((hipStream_t)stream, a)) : PAM_E_ARG;
     if (gs_ok && (tile_cfg == 8 || (tile_cfg == -1 && !classic && conv_gs_auto(a))))
         return CONV_KIND(PAM_CONV_KERNEL_GS), (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
     CONV_KIND(PAM_CONV_KERNEL_IGEMM);
