@@ -269,6 +269,10 @@ int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDes
  *   piece p holds, with q = p ^ ((row >> 1) & 7), h = q >> 2, g = q & 3, the input channels 64 sl + 16 g + 8 h .. + 7.
  * tile_cfg: 16-pixel tiles per wave tile (1..3), <= 0 = automatic.  replaces: conv3 + bn3 + residual + relu and the next conv1 + bn1 +
  * relu of the official Bottleneck (the HRNet backend is absent from the reference: call sites /root/reference/src/ivclabpose.py:131-132,210). */
+/* y = ReLU(W . x + bias), 64 -> 64 channels, pointwise (the first Bottleneck's conv1 on the stem output): w_img [64 rows][64 K] bf16, row
+ * 16 jt + qq = output channel 16 (qq >> 2) + 4 jt + (qq & 3), natural K order, the row's 16-byte piece at position p holds K values
+ * 8 q .. 8 q + 7 with q = p ^ ((row >> 1) & 7). */
+int pam_pointwise64_relu_nhwc_bf16(void* stream, const void* in, const void* w_img, const float* bias, void* out, long long n_pixels);
 int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const void* x0, const void* residual, const void* w3_img,
                                   const float* bias3, const void* w1_img, const float* bias1, void* out_x, void* out_y1,
                                   long long n_pixels, int tile_cfg);

@@ -98,6 +98,7 @@ _SIGS = {
     'pam_basic_block_chunk_layout': (_I, [_I, _P]),
     'pam_basic_block_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_basic_block_nhwc_bf16_ex': (_I, [_P, _I, _P, _I]),
+    'pam_pointwise64_relu_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, C.c_longlong]),
     'pam_bottleneck_tail_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I]),
     'pam_plan_begin': (_I, []),
     'pam_plan_stream': (_I, [_I]),

@@ -1416,6 +1416,11 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     if ((tile_cfg == 8 || tile_cfg == 9) && !gs_ok) return PAM_E_ARG;
     if (tile_cfg == 9)                                  // streamed implicit GEMM with 96-channel slabs: the gathered pixel tile feeds twice the MFMAs
         return Cout % 96 == 0 ? (CONV_KIND(PAM_CONV_KERNEL_GS), launch_conv_gs<6>((hipStream_t)stream, a)) : PAM_E_ARG;
+    // large-M strided layers with whole 96-channel slabs and no residual (merged fuse heads 48 -> 96 / 192 at 96 x 72, transition1's
+    // 256 -> 96): the 96-channel-slab form gathers every pixel tile half as often (26.3 -> 23.3, 16.2 -> 13.2, 46.2 -> 31.4 us at 20 crops;
+    // slower below ~100 pixel tiles, where the layer is a latency chain whatever its tile)
+    if (gs_ok && tile_cfg == -1 && !classic && !a.res && Cout % 96 == 0 && KH == 3 && stride == 2 && a.M >= 100 * 256)
+        return CONV_KIND(PAM_CONV_KERNEL_GS), launch_conv_gs<6>((hipStream_t)stream, a);
     if (gs_ok && (tile_cfg == 8 || (tile_cfg == -1 && !classic && conv_gs_auto(a))))
         return CONV_KIND(PAM_CONV_KERNEL_GS), (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
     CONV_KIND(PAM_CONV_KERNEL_IGEMM);

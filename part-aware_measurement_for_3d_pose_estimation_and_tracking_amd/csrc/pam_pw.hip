@@ -236,6 +236,69 @@ static int launch_pw2(hipStream_t s, const PwArgs& a, int max_wg) {
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
+// ---- k_pw1: y = ReLU(W . x + b), 64 -> 64 channels, pointwise (the first Bottleneck's conv1, whose input is the stem's 64-channel output).
+// 128 B in, 128 B out per pixel: a pure stream.  The whole weight matrix is 8 A fragments = 32 VGPRs per lane, loaded once (w_img: chunk 0 of
+// the w1 layout below WITHOUT the K permutation, i.e. row 16 jt + qq = output channel 16 (qq >> 2) + 4 jt + (qq & 3), natural K order, pieces
+// swizzled like every chunk image); every wave streams 16-pixel tiles on its own, four tiles in flight.
+struct Pw1Args { const uint16_t* in; const uint16_t* w; const float* b; uint16_t* out; int M; };
+__global__ __launch_bounds__(256) void k_pw1(Pw1Args a) {
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, px = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.M * 128), 0x00020000);
+    const auto rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((size_t)a.M * 128), 0x00020000);
+    bf16x8_t wf[2][4];
+    {
+        const unsigned s3 = (unsigned)px >> 1;
+        const unsigned fo0 = (unsigned)px * 128 + (((unsigned)g ^ (s3 & 3)) << 4) + ((s3 >> 2) << 6);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wf[h][j] = *(const bf16x8_t*)((const char*)a.w + j * 2048 + (h ? (fo0 ^ 64u) : fo0));
+    }
+    f32x4 bias[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias[j] = *(const f32x4*)(a.b + 16 * g + 4 * j);
+    constexpr int U = 4;                                 // 16-pixel tiles per iteration (all their loads issued before the first MFMA)
+    const int ntile = (a.M + 15) >> 4, stride = (int)gridDim.x * 4 * U;
+    for (int t0 = ((int)blockIdx.x * 4 + wave) * U; t0 < ntile; t0 += stride) {
+        u32x4 xb[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = (t0 + u) * 16 + px;
+            const unsigned o = (t0 + u < ntile && m < a.M) ? (unsigned)m * 128u + g * 16 : OOB_OFFSET;
+            xb[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, o, 0, 0);
+            xb[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, o, 64, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = bias[j];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[h][j], __builtin_bit_cast(bf16x8_t, xb[u][h]), acc[j], 0, 0, 0);
+            uint32_t o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[2 * j] = pw_relu2(pw_pack(acc[j][0], acc[j][1])); o[2 * j + 1] = pw_relu2(pw_pack(acc[j][2], acc[j][3])); }
+            const int m = (t0 + u) * 16 + px;
+            const unsigned oo = (t0 + u < ntile && m < a.M) ? (unsigned)m * 128u + g * 32 : OOB_OFFSET;
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){o[0], o[1], o[2], o[3]}, rs_out, oo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){o[4], o[5], o[6], o[7]}, rs_out, oo, 16, 0);
+        }
+    }
+}
+extern "C" int pam_pointwise64_relu_nhwc_bf16(void* stream, const void* in, const void* w_img, const float* bias, void* out, long long n_pixels) {
+    if (!in || !w_img || !bias || !out || n_pixels <= 0 || n_pixels * 128 >= (1ll << 31)) return PAM_E_ARG;
+    Pw1Args a; a.in = (const uint16_t*)in; a.w = (const uint16_t*)w_img; a.b = bias; a.out = (uint16_t*)out; a.M = (int)n_pixels;
+    const int ntile = (a.M + 15) >> 4;
+    int grid = (ntile + 15) / 16;                        // 4 waves x 4 tiles per workgroup and iteration
+    if (grid > 2048) grid = 2048;
+    pam_launch(k_pw1, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
 // Weight image layouts (what the host must pack; bf16):
 //   w3_img [S][256 rows][64 K] -- chunk c = K source c (0: conv3 over y2, 1: the downsample conv over x0); row 64 sl + 16 jt + qq (qq < 16)
 //     holds output channel 64 sl + 16 (qq >> 2) + 4 jt + (qq & 3); the row's 16-byte piece at PHYSICAL position p holds K values

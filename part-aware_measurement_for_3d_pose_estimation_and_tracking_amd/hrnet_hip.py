@@ -199,6 +199,19 @@ class LaunchPlan(object):
             pass
 
 
+class PackedPointwise64(object):
+    """A 64 -> 64 1x1 convolution (+ ReLU) packed for ``pam_pointwise64_relu_nhwc_bf16`` (csrc/pam_pw.hip, k_pw1)."""
+
+    def __init__(self, conv, device):
+        assert conv.weight.shape == (64, 64, 1, 1)
+        R = torch.arange(64)
+        ch = 16 * ((R % 16) >> 2) + 4 * (R // 16) + (R & 3)
+        q = torch.arange(8)[None, :] ^ ((R >> 1) & 7)[:, None]
+        w = conv.weight.detach().float().reshape(64, 64)[ch].reshape(64, 8, 8)
+        self.w = torch.gather(w, 1, q[:, :, None].expand(64, 8, 8)).to(torch.bfloat16).to(device).contiguous()
+        self.b = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(64)).to(device).contiguous()
+
+
 class ConvEngine(object):
     """Kernel launchers shared by the pose network (HipHRNet) and the person detector (yolov3.HipDarknet)."""
     count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
@@ -287,6 +300,27 @@ class ConvEngine(object):
                        sum(2 * (2 * x.numel() + 2 * 9 * o.c * o.c) + 8 * o.c for o, x in zip(ops, xs)),
                        sum(2 * 2 * x.numel() * 9 * o.c for o, x in zip(ops, xs)), launch)
         return ys
+
+    def pointwise64(self, op, x):
+        """ReLU(conv1x1 64 -> 64 (x)) as a pure stream (k_pw1)."""
+        n, c, h, w = x.shape
+        assert c == 64
+        y = torch.empty_like(x)
+        if self._keep is not None:
+            self._keep.append(y)
+        nbytes, flops = 2 * (2 * x.numel() + 64 * 64) + 4 * 64, 2 * n * h * w * 64 * 64
+        if self.count is not None:
+            self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
+        if x.device.type == 'meta':
+            return y
+        assert x.is_contiguous(memory_format=torch.channels_last)
+        launch = lambda: self.lib.pam_pointwise64_relu_nhwc_bf16(C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()),
+                                                                  C.c_void_p(op.w.data_ptr()), C.c_void_p(op.b.data_ptr()), C.c_void_p(y.data_ptr()), n * h * w)
+        rc = launch()
+        if rc != 0:
+            raise _lib.PamError('pam_pointwise64_relu_nhwc_bf16 failed (%d)' % rc)
+        self._prof_add(x, 'k_pw1 64->64 pointwise', (n, h, w), nbytes, flops, launch)
+        return y
 
     def bottleneck_tail(self, op, y2, x0=None, res=None, tile_cfg=0):
         """X = ReLU(conv3(y2) [+ downsample(x0)] [+ res]); y1 = ReLU(conv1_next(X)) in one launch -> (X, y1 or None)."""
@@ -454,6 +488,7 @@ class HipHRNet(ConvEngine):
                             down=P(b.downsample[0]) if b.downsample is not None else None) for b in m.layer1]
         # the same blocks for the fused pointwise tail: tail b = conv3_b [+ downsample_0] + residual + ReLU, then conv1_{b+1} + ReLU
         l1 = list(m.layer1)
+        self.pw0 = PackedPointwise64(l1[0].conv1, device)
         self.tails = [PackedTail(b.conv3, b.downsample[0] if b.downsample is not None else None,
                                  l1[i + 1].conv1 if i + 1 < len(l1) else None, device) for i, b in enumerate(l1)]
         self.t1 = [P(m.transition1[0][0]), P(m.transition1[1][0][0])]
@@ -883,7 +918,7 @@ class HipHRNet(ConvEngine):
             # layer1 as 1 + 4 x 2 launches: conv1 of the first block, then per block the 3x3 and ONE pointwise-tail launch (conv3 + residual
             # / downsample + ReLU + the next block's conv1): the 256-channel tensor is written once and read once per block
             x0, res = x, None
-            y = self.conv(self.layer1[0]['c1'], x0, relu=True)
+            y = self.pointwise64(self.pw0, x0)
             for i, b in enumerate(self.layer1):
                 y2 = self.conv(b['c2'], y, relu=True)
                 x, y = self.bottleneck_tail(self.tails[i], y2, x0 if i == 0 else None, res, self.tail_cfg)

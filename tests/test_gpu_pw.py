@@ -98,3 +98,21 @@ def test_layer1_fused_tail_matches_unfused_path():
     assert a.shape == b.shape == (3, 256, 96, 72)
     rel = float((a - b).norm() / b.norm())
     assert rel < 6e-3, rel
+
+
+@pytest.mark.parametrize('shape', [(1, 5, 3), (3, 7, 11), (2, 96, 72), (20, 96, 72)])
+def test_pointwise64_vs_torch(eng, shape):
+    e, hh = eng
+    n, h, w = shape
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(n * 100 + h)
+    conv = nn.Conv2d(64, 64, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.2); conv.bias.copy_(torch.randn(64, generator=g))
+    op = hh.PackedPointwise64(conv, dev)
+    x = torch.randn((n, 64, h, w), generator=g)
+    y = e.pointwise64(op, x.to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+    ref = torch.relu(F.conv2d(_bf(x), _bf(conv.weight), conv.bias)).detach()
+    err = (y.float().cpu() - ref).abs()
+    assert float(err.max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-2, float(err.max())
