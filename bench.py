@@ -674,27 +674,34 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
             model(x); reps += 1
         return (time.perf_counter() - t0) / reps, reps
     runs = []
-    with torch.no_grad():
-        # All usable cores is the prescribed configuration, but on a many-core box an oversubscribed team can be orders of magnitude
-        # slower (measured on the 256-core GPU host: one batch-20 forward took 209 s at 256 threads vs 1.5 s at 16).  A ONE-crop probe
-        # at all cores against 16 threads decides whether the full batch is run at all cores; either way the batch is really run
-        # (never extrapolated) at the thread counts below and the fastest is the baseline.
-        def one_crop(thr, warm):
-            torch.set_num_threads(thr)
-            if warm:
-                model(x[:1])
-            t0 = time.perf_counter(); model(x[:1]); return time.perf_counter() - t0
-        small = min(16, avail)
-        p_small = one_crop(small, True)
-        p_all = one_crop(avail, False) if avail > small else p_small      # a single forward: at 256 threads even one crop takes ~10 s
-        probe = {'one_crop_s_at_%d_threads' % small: p_small, 'one_crop_s_at_%d_threads' % avail: p_all}
-        best = None
-        if p_all <= 2.0 * p_small:
-            t_all, reps_all = batch_time(avail, 12.0)
-            runs.append({'threads': avail, 's_per_batch': t_all, 'timed_forwards': reps_all})
+    # All usable cores is the prescribed configuration, but on the many-core GPU hosts an oversubscribed OpenMP team is orders of magnitude
+    # slower (measured: ONE crop took 201 s at 256 threads vs 0.08 s at 16; a batch-20 forward 209 s vs 1.5 s).  The all-cores batch
+    # therefore runs in a CHILD process with a hard time limit (a forward cannot be interrupted from inside); the smaller teams run here.
+    # Every figure is a real batch of `crops` crops, never an extrapolation; the fastest is the baseline.
+    quota = None
+    try:
+        q = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q[0] != 'max':
+            quota = float(q[0]) / float(q[1])
+    except Exception:
+        pass
+    best = None
+    limit_s = 25.0
+    code = ("import sys, time, torch; sys.path.insert(0, %r); import pam; from pam import hrnet as H; torch.set_num_threads(%d); "
+            "m = H.fold_batchnorm(H.init_random(H.PoseHighResolutionNet())).eval(); x = torch.randn(%d, 3, 384, 288)\n"
+            "with torch.no_grad():\n    m(x[:1]); t0 = time.perf_counter(); m(x); print('BATCH_S', time.perf_counter() - t0)" % (ROOT, avail, crops))
+    try:
+        pr = subprocess.run([sys.executable, '-c', code], timeout=limit_s, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        got = [l for l in pr.stdout.splitlines() if l.startswith('BATCH_S')]
+        if got:
+            t_all = float(got[-1].split()[1])
+            runs.append({'threads': avail, 's_per_batch': t_all, 'timed_forwards': 1, 'where': 'child process'})
             best = (t_all, avail)
         else:
-            runs.append({'threads': avail, 's_per_batch': None, 'skipped': 'one-crop probe %.2f s vs %.2f s at %d threads: oversubscribed' % (p_all, p_small, small)})
+            runs.append({'threads': avail, 's_per_batch': None, 'skipped': 'child process failed (rc %d)' % pr.returncode})
+    except subprocess.TimeoutExpired:
+        runs.append({'threads': avail, 's_per_batch': None, 'skipped': 'not finished within %.0f s (oversubscribed team)' % limit_s})
+    with torch.no_grad():
         for thr in [c for c in (16, 32, 64) if c < avail] or [avail]:
             if any(r['threads'] == thr and r.get('s_per_batch') for r in runs):
                 continue
@@ -702,6 +709,7 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
             runs.append({'threads': thr, 's_per_batch': t_thr, 'timed_forwards': reps})
             if best is None or t_thr < best[0]:
                 best = (t_thr, thr)
+    probe = {'cgroup_cpu_quota_cores': quota}
     t_hr, thr = best
     return {'value': 1.0 / (t_hr + t_match), 'unit': 'frames/s', 'cores': avail, 'cpu_count': ncpu, 'affinity_cores': avail,
             'threads': thr, 'kind': 'port',
