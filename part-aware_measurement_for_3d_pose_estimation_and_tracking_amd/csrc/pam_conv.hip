@@ -1005,11 +1005,12 @@ static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, 
 // fragment addresses are constants + immediates.  One s_barrier per chunk (loaders: chunk k has landed; multipliers: chunk k - 1 is
 // consumed), residual folded into the bias before the K loop, epilogue = convert + ReLU (channels >= relu_from) + 16-byte stores.
 // ====================================================================================================================
-template <int NTW, int NBUF, bool RES>
+template <int NTW, int NBUF, bool RES, int BM>
 __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
-    constexpr int BM = 256, BN = 16 * NTW, AIMG = BM * 128, BIMG = BN * 128, BUF = AIMG + BIMG;
+    constexpr int MTW = BM / 64;                            // 16-pixel tiles per multiplier wave (4 at BM = 256, 2 at 128, 1 at 64)
+    constexpr int BN = 16 * NTW, AIMG = BM * 128, BIMG = BN * 128, BUF = AIMG + BIMG;
     constexpr int APW = AIMG / 1024 / 4, BPIECES = BIMG / 1024, BPW = (BPIECES + 3) / 4, NPER = APW + BPW;
-    static_assert(NPER * (NBUF - 1) <= 60 && NBUF >= 2 && NBUF <= 4, "ring shape");
+    static_assert(NPER * (NBUF - 1) <= 60 && NBUF >= 2 && NBUF <= 6 && (BM == 256 || BM == 128 || BM == 64), "ring shape");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1097,7 +1098,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
             const int fly = min(total - 1 - k, NBUF - 2);                                // younger chunks that may stay in flight
             if (fly <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPER) : "memory");
+            else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPER) : "memory");
+            else if (fly == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF >= 5 ? 3 * NPER : 0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBUF >= 6 ? 4 * NPER : 0) : "memory");
             asm volatile("s_barrier" ::: "memory");
             if (issued < total) issue_next();
         }
@@ -1106,11 +1109,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
 
     // ---- multiplier waves ---------------------------------------------------------------------------------------------------
     const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.out), 0, (int)((size_t)a.M * a.Cout * 2), 0x00020000);
-    uint32_t rres[4][2 * NTW];
+    uint32_t rres[MTW][2 * NTW];
     auto res_load = [&](int t) {                                                         // residual rows of my tile t -> registers (in flight)
-        const int T = tile_of(t), mw0 = (T / nslab) * BM + wave * 64, n0 = (T % nslab) * BN;
+        const int T = tile_of(t), mw0 = (T / nslab) * BM + wave * 16 * MTW, n0 = (T % nslab) * BN;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MTW; ++i) {
             const int m = mw0 + i * 16 + (lane & 15);
             c3_row_load<NTW>(rs_res, m < a.M ? (unsigned)(((size_t)m * a.Cout + n0 + g * 4 * NTW) * 2) : OOB_OFFSET, g, rres[i]);
         }
@@ -1118,21 +1121,21 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
     if (RES && a.res) res_load(0);
     // fragment addresses: row (lane & 15) of a 16-row window, k-group g of k-step ks -> piece (4 ks + g) ^ ((lane & 15) >> 1)
     const unsigned sw = (unsigned)((g ^ ((lane & 15) >> 1)) << 4);                       // ks = 0; ks = 1 is sw ^ 64
-    const unsigned aoff0 = (unsigned)((wave * 64 + (lane & 15)) * 128) + sw;
+    const unsigned aoff0 = (unsigned)((wave * 16 * MTW + (lane & 15)) * 128) + sw;
     const unsigned boff0 = (unsigned)(AIMG + (lane & 15) * 128) + sw;
-    f32x4 acc[4][NTW];
-    bf16x8 af[2][4], bfr[2][NTW];
+    f32x4 acc[MTW][NTW];
+    bf16x8 af[2][MTW], bfr[2][NTW];
     auto ldfrag = [&](int G, int ks, bf16x8* af_, bf16x8* bf_) {
         const char* buf = smem + (size_t)((unsigned)G % (unsigned)NBUF) * BUF;
         const unsigned x = ks ? 64u : 0u;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) bf_[j] = *(const bf16x8*)(buf + ((boff0 ^ x) + j * 16 * 128));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af_[i] = *(const bf16x8*)(buf + ((aoff0 ^ x) + i * 16 * 128));
+        for (int i = 0; i < MTW; ++i) af_[i] = *(const bf16x8*)(buf + ((aoff0 ^ x) + i * 16 * 128));
     };
     auto mfmas = [&](const bf16x8* af_, const bf16x8* bf_) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MTW; ++i)
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bf_[j]), __builtin_bit_cast(bf16x8_t, af_[i]), acc[i][j], 0, 0, 0);
@@ -1141,13 +1144,13 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
     asm volatile("s_barrier" ::: "memory");                                              // my first chunk has landed (and is visible)
     int G = 0;
     for (int t = 0; t < mine; ++t) {
-        const int T = tile_of(t), mw0 = (T / nslab) * BM + wave * 64, n0 = (T % nslab) * BN;
+        const int T = tile_of(t), mw0 = (T / nslab) * BM + wave * 16 * MTW, n0 = (T % nslab) * BN;
         {   // accumulators start from bias (+ residual, requested a tile ago)
             f32x4 bias4[NTW];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MTW; ++i)
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     acc[i][j] = bias4[j];
@@ -1163,7 +1166,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
         for (int c = 0; c < nchunks; ++c, ++G) {
             ldfrag(G, 1, af[1], bfr[1]);
             mfmas(af[0], bfr[0]);
-            c3s_spread<4 * NTW, 4 + NTW>(std::make_integer_sequence<int, 4 + NTW>{});
+            c3s_spread<MTW * NTW, MTW + NTW>(std::make_integer_sequence<int, MTW + NTW>{});
             __builtin_amdgcn_sched_barrier(0);
             if (G + 1 < total) {
                 __builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0): this wave is done reading chunk G
@@ -1176,7 +1179,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
         }
         // epilogue: this lane holds channels n0 + 4*NTW*g + 4*j + r of pixel mw0 + i*16 + (lane & 15)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MTW; ++i) {
             const int m = mw0 + i * 16 + (lane & 15);
             if (m < a.M) {
                 uint32_t ov[2 * NTW];
@@ -1207,17 +1210,17 @@ static bool conv_gs_auto(const ConvArgs& a) {
     const int rounds = (tiles + 255) / 256;
     return nslab == 1 || tiles <= 256 || tiles * 100 >= rounds * 256 * 78;
 }
-template <int NTW, bool RES>
+template <int NTW, bool RES, int BM = 256, int NBUF = 3>
 static int launch_conv_gs_r(hipStream_t s, const ConvArgs& a) {
-    constexpr int NBUF = 3;
-    constexpr size_t lds = (size_t)NBUF * (256 + 16 * NTW) * 128;
+    constexpr size_t lds = (size_t)NBUF * (BM + 16 * NTW) * 128;
+    static_assert(lds <= 160 * 1024, "LDS");
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_conv_gs<NTW, NBUF, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
+        if (hipFuncSetAttribute((const void*)k_conv_gs<NTW, NBUF, RES, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
         attr = true;
     }
-    const int ntile = ((a.M + 255) / 256) * (a.Cout / (16 * NTW));
-    pam_launch(k_conv_gs<NTW, NBUF, RES>, dim3(ntile < 256 ? ntile : 256), dim3(512), lds, s, a);
+    const int ntile = ((a.M + BM - 1) / BM) * (a.Cout / (16 * NTW));
+    pam_launch(k_conv_gs<NTW, NBUF, RES, BM>, dim3(ntile < 256 ? ntile : 256), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 template <int NTW>
@@ -1413,7 +1416,17 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     if (tile_cfg >= 100) tile_cfg = -1;
     // streamed implicit GEMM (k_conv_gs): codes 0 / 1, taps in a 32-bit mask, whole 16-byte pieces per tap (Cin % 8 == 0)
     const bool gs_ok = relu <= 1 && KH * KW <= 9 && Cin % 8 == 0 && (size_t)N * H * W * in_cstride * 2 < (1u << 31);
-    if ((tile_cfg == 8 || tile_cfg == 9) && !gs_ok) return PAM_E_ARG;
+    if (tile_cfg >= 8 && tile_cfg <= 12 && !gs_ok) return PAM_E_ARG;
+    if (tile_cfg == 12) {                               // 64-pixel tiles: the smallest images (12 x 9) as a few hundred short workgroups
+        if (a.res || Cout % 48 != 0) return PAM_E_ARG;
+        CONV_KIND(PAM_CONV_KERNEL_GS);
+        return launch_conv_gs_r<3, false, 64, 3>((hipStream_t)stream, a);
+    }
+    if (tile_cfg == 10 || tile_cfg == 11) {             // 128-pixel tiles, ring of 5 (10) / 3 (11) chunks: twice the workgroups, deeper prefetch
+        if (a.res || Cout % 48 != 0) return PAM_E_ARG;
+        CONV_KIND(PAM_CONV_KERNEL_GS);
+        return tile_cfg == 10 ? launch_conv_gs_r<3, false, 128, 5>((hipStream_t)stream, a) : launch_conv_gs_r<3, false, 128, 3>((hipStream_t)stream, a);
+    }
     if (tile_cfg == 9)                                  // streamed implicit GEMM with 96-channel slabs: the gathered pixel tile feeds twice the MFMAs
         return Cout % 96 == 0 ? (CONV_KIND(PAM_CONV_KERNEL_GS), launch_conv_gs<6>((hipStream_t)stream, a)) : PAM_E_ARG;
     // large-M strided layers with whole 96-channel slabs and no residual (merged fuse heads 48 -> 96 / 192 at 96 x 72, transition1's
@@ -1421,8 +1434,18 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     // slower below ~100 pixel tiles, where the layer is a latency chain whatever its tile)
     if (gs_ok && tile_cfg == -1 && !classic && !a.res && Cout % 96 == 0 && KH == 3 && stride == 2 && a.M >= 100 * 256)
         return CONV_KIND(PAM_CONV_KERNEL_GS), launch_conv_gs<6>((hipStream_t)stream, a);
-    if (gs_ok && (tile_cfg == 8 || (tile_cfg == -1 && !classic && conv_gs_auto(a))))
-        return CONV_KIND(PAM_CONV_KERNEL_GS), (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
+    if (gs_ok && (tile_cfg == 8 || (tile_cfg == -1 && !classic && conv_gs_auto(a)))) {
+        CONV_KIND(PAM_CONV_KERNEL_GS);
+        if (tile_cfg == -1 && !a.res && Cout % 48 == 0) {
+            // the small fuse-layer convolutions are latency chains of a few workgroups: the smallest pixel tile that still is ONE round of
+            // workgroups (<= 256) -- at 20 crops 192 -> 384 at 12 x 9 21.3 -> 16.9 us, 48 -> 48 at 24 x 18 10.0 -> 6.1 us, 384 -> 336 1x1
+            // 8.8 -> 5.8 us; two rounds lose (tools/bench_conv.py --fuse --tiles=-1,11,12)
+            const int nslab = Cout / 48;
+            if (((a.M + 63) / 64) * nslab <= 256) return launch_conv_gs_r<3, false, 64, 3>((hipStream_t)stream, a);
+            if (((a.M + 127) / 128) * nslab <= 256) return launch_conv_gs_r<3, false, 128, 3>((hipStream_t)stream, a);
+        }
+        return (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
+    }
     CONV_KIND(PAM_CONV_KERNEL_IGEMM);
     return (Cout % 48 == 0) ? dispatch_conv<3>((hipStream_t)stream, a, tile_cfg) : dispatch_conv<4>((hipStream_t)stream, a, tile_cfg);
 }

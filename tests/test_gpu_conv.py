@@ -61,10 +61,12 @@ def eng():
 
 
 @pytest.mark.parametrize('case', CASES)
-@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_conv_vs_torch(eng, case, tile):
     from pam import _lib, hrnet_hip
     n, h, w, cin, cout, k, stride, use_res, relu = case
+    if tile in (10, 11, 12) and (cout % 48 or use_res or cin == 8):
+        pytest.skip('128- / 64-pixel-tile streamed implicit GEMM: 48-channel slabs, no residual')
     if tile == 9 and (cout % 96 or use_res or cin == 8 or (k == 3 and stride == 1)):
         pytest.skip('96-channel-slab streamed implicit GEMM: fuse-layer shapes (Cout % 96 == 0, no residual)')
     nb = cout // (48 if cout % 48 == 0 else 64)
