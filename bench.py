@@ -171,26 +171,50 @@ class H2DFeeder(object):
 
     def __init__(self, torch, frames_dev, dev):
         self.torch, self.dev = torch, dev
-        self.host = [f.cpu().pin_memory() for f in frames_dev]
-        self.sets = [frames_dev, [torch.empty_like(f) for f in frames_dev]]
+        # ONE pinned staging buffer and ONE device buffer per set holding all of the rank's views back to back: one copy per frame
+        # (PAM_H2D_MODE=multi: one copy per view, the first form tried; serial: the single copy on the compute stream, not overlapped)
+        self.mode = os.environ.get('PAM_H2D_MODE', 'single')
+        sizes = [int(f.numel()) for f in frames_dev]
+        self.bytes_per_frame = sum(sizes)
+        self.host_all = torch.empty(max(1, self.bytes_per_frame), dtype=torch.uint8).pin_memory()
+        off, self.host = 0, []
+        for f, sz in zip(frames_dev, sizes):
+            self.host_all[off:off + sz].copy_(f.reshape(-1).cpu()); self.host.append(self.host_all[off:off + sz].view(f.shape)); off += sz
+        self.dev_all = [torch.empty(max(1, self.bytes_per_frame), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.sets = []
+        for k in range(2):
+            off, fs = 0, []
+            for f, sz in zip(frames_dev, sizes):
+                fs.append(self.dev_all[k][off:off + sz].view(f.shape)); off += sz
+            self.sets.append(fs)
         self.ptrs = [torch.tensor([f.data_ptr() for f in fs] or [0], dtype=torch.int64, device=dev) for fs in self.sets]
         self.copy = torch.cuda.Stream(dev)
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]
         self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
         self.used = [False, False]
-        self.bytes_per_frame = sum(int(f.numel()) for f in frames_dev)
+
+    def _copy(self, k):
+        if self.mode == 'multi':
+            for d, h in zip(self.sets[k], self.host):
+                d.copy_(h, non_blocking=True)
+        else:
+            self.dev_all[k].copy_(self.host_all, non_blocking=True)
 
     def prefetch(self, t):
         k = t & 1
+        if self.mode == 'serial':
+            return
         with self.torch.cuda.stream(self.copy):
             if self.used[k]:
                 self.copy.wait_event(self.consumed[k])
-            for d, h in zip(self.sets[k], self.host):
-                d.copy_(h, non_blocking=True)
+            self._copy(k)
             self.ready[k].record(self.copy)
 
     def acquire(self, t):
-        self.torch.cuda.current_stream(self.dev).wait_event(self.ready[t & 1])
+        if self.mode == 'serial':
+            self._copy(t & 1)
+        else:
+            self.torch.cuda.current_stream(self.dev).wait_event(self.ready[t & 1])
         return self.ptrs[t & 1]
 
     def release(self, t):
@@ -399,7 +423,7 @@ def main():
                        'conv_backend': pipe.net.backend if pipe.net else None,
                        'exchange': ('one all-gather per frame (%s)' % ('pam_allgather_keypoints: RCCL called inside the C ABI' if pipe.comm else 'torch.distributed ' + backend)) if world > 1 else 'none',
                        'devices': '%d ranks on ONE device (no multi-GPU box: functional check only)' % world if single_dev and world > 1 else '%d' % world},
-            'roofline': {'kernel': 'HRNet-W48 conv stack: k_bblock / k_conv3x3 / k_conv_igemm / k_upsample_add (hipGraph replay, %d crops, %d launches)'
+            'roofline': {'kernel': 'HRNet-W48 conv stack: k_bblock / k_conv3x3[s] / k_conv_gs / k_conv_igemm / k_pw1 / k_pw2 / k_upsample_add (hipGraph replay, %d crops, %d launches)'
                                    % (n_med, launches),
                          'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': avg_ms,

@@ -1432,10 +1432,13 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     // large-M strided layers with whole 96-channel slabs and no residual (merged fuse heads 48 -> 96 / 192 at 96 x 72, transition1's
     // 256 -> 96): the 96-channel-slab form gathers every pixel tile half as often (26.3 -> 23.3, 16.2 -> 13.2, 46.2 -> 31.4 us at 20 crops;
     // slower below ~100 pixel tiles, where the layer is a latency chain whatever its tile)
+#ifndef PAM_GS_OLDTILES                                  /* A/B hook (tools/ab_build.sh): round-2 tile choice */
     if (gs_ok && tile_cfg == -1 && !classic && !a.res && Cout % 96 == 0 && KH == 3 && stride == 2 && a.M >= 100 * 256)
         return CONV_KIND(PAM_CONV_KERNEL_GS), launch_conv_gs<6>((hipStream_t)stream, a);
+#endif
     if (gs_ok && (tile_cfg == 8 || (tile_cfg == -1 && !classic && conv_gs_auto(a)))) {
         CONV_KIND(PAM_CONV_KERNEL_GS);
+#ifndef PAM_GS_OLDTILES
         if (tile_cfg == -1 && !a.res && Cout % 48 == 0) {
             // the small fuse-layer convolutions are latency chains of a few workgroups: the smallest pixel tile that still is ONE round of
             // workgroups (<= 256) -- at 20 crops 192 -> 384 at 12 x 9 21.3 -> 16.9 us, 48 -> 48 at 24 x 18 10.0 -> 6.1 us, 384 -> 336 1x1
@@ -1444,6 +1447,7 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
             if (((a.M + 63) / 64) * nslab <= 256) return launch_conv_gs_r<3, false, 64, 3>((hipStream_t)stream, a);
             if (((a.M + 127) / 128) * nslab <= 256) return launch_conv_gs_r<3, false, 128, 3>((hipStream_t)stream, a);
         }
+#endif
         return (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
     }
     CONV_KIND(PAM_CONV_KERNEL_IGEMM);

@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--shape', default='96,72,48,48,3,1'); ap.add_argument('--n', type=int, default=20)
 ap.add_argument('--iters', type=int, default=20); ap.add_argument('--tile', type=int, default=-1); ap.add_argument('--res', type=int, default=1)
 ap.add_argument('--block', type=int, default=0, help='1: the fused BasicBlock kernel on (h, w, cin) instead of one convolution')
+ap.add_argument('--tail', type=int, default=0, help='1: the fused pointwise tail of a layer1 Bottleneck (k_pw2: conv3 + residual + next conv1) on (h, w); 2: k_pw1 (64 -> 64 pointwise)')
 a = ap.parse_args()
 h, w, cin, cout, k, s = [int(x) for x in a.shape.split(',')]
 dev = torch.device('cuda:0')
@@ -18,6 +19,22 @@ if a.block:
     xb = torch.randn((a.n, cin, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
     for _ in range(a.iters):
         yb = e.basic_blocks([bop], [xb], 8)
+    torch.cuda.synchronize()
+    sys.exit(0)
+if a.tail:
+    cl = lambda c: torch.randn((a.n, c, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    if a.tail == 1:
+        top = hrnet_hip.PackedTail(nn.Conv2d(64, 256, 1), None, nn.Conv2d(256, 64, 1), dev)
+        y2, r = cl(64), cl(256)
+        for _ in range(a.iters):
+            e._keep = []
+            e.bottleneck_tail(top, y2, None, r, 0)
+    else:
+        pop = hrnet_hip.PackedPointwise64(nn.Conv2d(64, 64, 1), dev)
+        x0 = cl(64)
+        for _ in range(a.iters):
+            e._keep = []
+            e.pointwise64(pop, x0)
     torch.cuda.synchronize()
     sys.exit(0)
 conv = nn.Conv2d(cin, cout, k, s, k // 2, bias=True)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-end artefacts (GPU box, through gpurun): bench line, the same command under rocprofv3 --kernel-trace --stats, PMC passes
 # (whole-forward HBM traffic, per-family counters), the N = 2 bench on one device.  usage: tools/refresh_profiles.sh <git commit> <tag>
-COMMIT=${1:-unknown}; TAG=${2:-r02}
+COMMIT=${1:-unknown}; TAG=${2:-r03}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; mkdir -p $OUT
 cd $R
 bash tools/pmc_hrnet.sh $COMMIT $TAG > $OUT/pmc_hrnet.log 2>&1
@@ -11,6 +11,7 @@ python3 bench.py > $OUT/${TAG}_bench_S2_n1.json 2> $OUT/bench.err
 cp $(ls -t $OUT/stats/*/*kernel_stats.csv | head -1) $OUT/${TAG}_bench_S2_kernel_stats.csv
 python3 bench.py --gpus 2 > $OUT/${TAG}_bench_S4_n2_one_device.json 2> $OUT/bench2.err
 bash tools/pmc_families.sh $COMMIT $TAG > $OUT/pmc_families.log 2>&1
-cp gpurun_out/pmc_fam/${TAG}_pmc_families.json gpurun_out/pmc_hrnet/${TAG}_hrnet_hbm_traffic.json $OUT/ 2>/dev/null
+bash tools/pmc_frame.sh $COMMIT $TAG > $OUT/pmc_frame.log 2>&1
+cp gpurun_out/pmc_fam/${TAG}_pmc_families.json gpurun_out/pmc_hrnet/${TAG}_hrnet_hbm_traffic.json gpurun_out/pmc_frame/${TAG}_pmc_k_frame.json $OUT/ 2>/dev/null
 rm -rf $OUT/stats
 ls -la $OUT
