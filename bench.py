@@ -166,8 +166,11 @@ def build_inputs(torch, synth, seq, size, max_dets, world, rank, shard, dev, nF)
 class H2DFeeder(object):
     """The frames start in PINNED HOST memory (as after a decode thread, /root/reference/src/testmodel.py:51-63 starts from host images):
     frame t + 1's C images are copied host -> device on a copy stream while frame t's conv stack runs, into the other of two device
-    frame sets; the crop kernel of a frame waits for its set's copy, the copy of a set waits until the crop kernel that last read it
-    is done.  Used for `value_with_h2d`; `value` keeps the frames resident (the contract's definition)."""
+    frame sets; the crop kernel of a frame waits (on the device) for its set's copy; before a set is overwritten the HOST waits for
+    the event recorded behind the crop kernel that last read it -- two frames back, so it is normally long done.  (A device-side
+    wait of the copy stream on that event serialises the copy with the conv stack on this ROCm: 3.22 vs 2.65 ms per frame, measured;
+    a copy with no device-side dependency overlaps fully, tools/h2d_probe.py.)
+    Used for `value_with_h2d`; `value` keeps the frames resident (the contract's definition)."""
 
     def __init__(self, torch, frames_dev, dev):
         self.torch, self.dev = torch, dev
@@ -204,9 +207,12 @@ class H2DFeeder(object):
         k = t & 1
         if self.mode == 'serial':
             return
-        with self.torch.cuda.stream(self.copy):
-            if self.used[k]:
+        if self.used[k]:
+            if 'devwait' in self.mode:
                 self.copy.wait_event(self.consumed[k])
+            else:
+                self.consumed[k].synchronize()          # host-side: the crop kernel of frame t - 2 has read this set
+        with self.torch.cuda.stream(self.copy):
             self._copy(k)
             self.ready[k].record(self.copy)
 
@@ -236,18 +242,14 @@ def make_step(pipe, inp, shard, feeder=None, last=None):
         def step(t, ev=None):
             e = pf[t]
             with pipe.frame():
-                pipe.pose_step(frames_of(t), e['vl'], e['sl'], e['bx'], ev)
-                if feeder is not None:
-                    feeder.release(t)
+                pipe.pose_step(frames_of(t), e['vl'], e['sl'], e['bx'], ev, (lambda: feeder.release(t)) if feeder is not None else None)
                 pipe.write_local(e['dd'])           # the tracker consumes the seeded synthetic keypoints, not the random net's
                 pipe.track_step(t, e['nd'])
     else:
         def step(t, ev=None):
             e = pf[t]
             with pipe.frame():
-                pipe.pose_step_crops(frames_of(t), e['vl'], e['sl'], e['bx'], ev)
-                if feeder is not None:
-                    feeder.release(t)
+                pipe.pose_step_crops(frames_of(t), e['vl'], e['sl'], e['bx'], ev, (lambda: feeder.release(t)) if feeder is not None else None)
                 pipe.write_send(e['dd'])            # ordered behind the previous frame's exchange / tracker, which read that buffer
                 pipe.track_step_crops(t, e['nd'], e['sel'])
     return step

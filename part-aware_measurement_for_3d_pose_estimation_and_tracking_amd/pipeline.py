@@ -67,12 +67,14 @@ class FramePipeline(object):
     def stream_ptr(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _pose(self, frame_ptrs, views, slot_of, boxes, det, time_events):
+    def _pose(self, frame_ptrs, views, slot_of, boxes, det, time_events, after_crop=None):
         """crop -> conv stack -> head + arg-max for one frame on the current stream, replay slot = frame parity when two pose streams run."""
         k = (self._frame_no & 1) if self.pose_streams is not None else 0
         n = int(views.numel())
         x = self.net.input_buffer(n, k)
         self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, views, boxes, x)
+        if after_crop is not None:
+            after_crop()                                # the frames have been read: a feeder may mark its buffers reusable here
         if time_events is not None:
             time_events[0].record(torch.cuda.current_stream(self.device))
         f = self.net.features(x, k)
@@ -96,11 +98,11 @@ class FramePipeline(object):
             yield
         self._frame_no += 1
 
-    def pose_step(self, frame_ptrs, view_local, slot_of, boxes, time_events=None):
+    def pose_step(self, frame_ptrs, view_local, slot_of, boxes, time_events=None, after_crop=None):
         """HRNet side for this rank's crops.  view_local: int32 (N,) index into self.mine; writes self.det_local."""
         if int(view_local.numel()) == 0 or self.net is None:
             return
-        self._pose(frame_ptrs, view_local, slot_of, boxes, self.det_local, time_events)
+        self._pose(frame_ptrs, view_local, slot_of, boxes, self.det_local, time_events, after_crop)
 
     def write_local(self, rows):
         """Copy keypoint rows (len(mine), max_dets, 17, 3) into this rank's records, ordered behind the previous frame's readers."""
@@ -141,12 +143,12 @@ class FramePipeline(object):
         self.wait_track()
         self.crop_gather.send.copy_(rows)
 
-    def pose_step_crops(self, frame_ptrs, view_of, slot_of, boxes, time_events=None):
+    def pose_step_crops(self, frame_ptrs, view_of, slot_of, boxes, time_events=None, after_crop=None):
         """HRNet side for this rank's share of the frame's crops; view_of indexes ALL views (frame_ptrs has C entries).
         Decodes straight into the exchange buffer at (view, slot)."""
         if int(view_of.numel()) == 0 or self.net is None:
             return
-        self._pose(frame_ptrs, view_of, slot_of, boxes, self.crop_gather.send, time_events)
+        self._pose(frame_ptrs, view_of, slot_of, boxes, self.crop_gather.send, time_events, after_crop)
 
     def track_step_crops(self, frame_id, n_det, select, fetch=True):
         """n_det (C,) int32 and select (CropGather.select_index) are the same on every rank (they follow from the frame's box
