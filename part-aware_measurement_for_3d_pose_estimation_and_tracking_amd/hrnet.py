@@ -545,16 +545,18 @@ class DumpResults(list):
         return True
 
 
-def measure_bf16_drift(net, n_crops=2, seed=2):
+def measure_bf16_drift(net, n_crops=2, seed=2, checker_device='cpu'):
     """Self-consistency number of the bf16 conv stack (parity with the authors' backend is unpinned: no weights offline): the same
-    folded weights run as a plain fp32 PyTorch module on the same device (the checker) vs ``net``'s product path, on seeded random
-    crops.  -> relative L2 error of the heat-maps, fraction of (crop, joint) arg-max cells that moved, and the largest move in
-    heat-map cells.  With random weights the heat-maps are nearly flat noise, so the arg-max fraction is a pessimistic figure."""
+    folded weights run as a plain fp32 PyTorch module (the checker; on the CPU by default, so that no PyTorch-ROCm / MIOpen kernel
+    appears in a profile of the run) vs ``net``'s product path, on seeded random crops.  -> relative L2 error of the heat-maps,
+    fraction of (crop, joint) arg-max cells that moved, and the largest move in heat-map cells.  With random weights the heat-maps are
+    nearly flat noise, so the arg-max fraction is a pessimistic figure."""
     dev = net.device
+    cdev = torch.device(checker_device)
     seed_w = int(net.weights.split('=')[1].rstrip(')')) if net.weights.startswith('random') else 0
     if not net.weights.startswith('random'):
         raise RuntimeError('measure_bf16_drift rebuilds the fp32 module from the seed; load the checkpoint into both to use it with real weights')
-    ref = fold_batchnorm(init_random(PoseHighResolutionNet(), seed=seed_w)).to(dev).eval()
+    ref = fold_batchnorm(init_random(PoseHighResolutionNet(), seed=seed_w)).to(cdev).eval()
     g = torch.Generator().manual_seed(seed)
     x32 = torch.randn((n_crops, 3, net.resolution[0], net.resolution[1]), generator=g).to(dev)
     xb = x32.to(torch.bfloat16)
@@ -562,7 +564,13 @@ def measure_bf16_drift(net, n_crops=2, seed=2):
         if net.in_channels > 3 else xb
     x8 = x8.contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        h32 = ref(xb.float())
+        if cdev.type == 'cpu':
+            nthr = torch.get_num_threads()
+            torch.set_num_threads(min(16, os.cpu_count() or 16))       # many-core hosts: a full team is slower by orders of magnitude
+            h32 = ref(xb.float().to(cdev)).to(dev)
+            torch.set_num_threads(nthr)
+        else:
+            h32 = ref(xb.float())
         hb = net.heatmaps(x8).float()
     w = h32.shape[3]
     a32, ab = h32.flatten(2).argmax(2), hb.flatten(2).argmax(2)
@@ -571,7 +579,7 @@ def measure_bf16_drift(net, n_crops=2, seed=2):
     return dict(crops=n_crops, rel_l2_err=float((hb - h32).norm() / h32.norm()), argmax_moved_frac=float(moved.float().mean()),
                 argmax_max_cells=int(cells.max()), argmax_mean_cells_when_moved=float(cells[moved].float().mean()) if bool(moved.any()) else 0.0,
                 score_max_abs_err=float((hb.flatten(2).max(2)[0] - h32.flatten(2).max(2)[0]).abs().max()),
-                weights=net.weights, checker='same folded weights as a plain fp32 PyTorch module on the GPU')
+                weights=net.weights, checker='same folded weights as a plain fp32 PyTorch module on the %s' % cdev.type)
 
 
 def smoke_check():
