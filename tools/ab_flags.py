@@ -25,7 +25,12 @@ for v in args.variants:
             form = val
         else:
             cur = getattr(hip, k)
-            setattr(hip, k, type(cur)(int(val)) if isinstance(cur, (bool, int)) else val)
+            if isinstance(cur, tuple):
+                setattr(hip, k, tuple(int(c) for c in val))          # e.g. order=3210, lane_of=0121
+            elif cur is None or isinstance(cur, (bool, int)):
+                setattr(hip, k, (type(cur)(int(val)) if cur is not None else int(val)))
+            else:
+                setattr(hip, k, val)
     x = net.input_buffer(args.n); x.copy_(torch.randn(x.shape, device=dev).to(x.dtype)); x[:, 3:] = 0
     hip.features(x); torch.cuda.synchronize()
     if form == 'graph':
