@@ -556,9 +556,10 @@ class HipHRNet(ConvEngine):
     lane_of = (0, 1, 2, 3)      # stream of branch b (0 = the caller's stream); issue order of the branches inside a module
     order = (0, 1, 2, 3)
     fuse_blocks = True          # BasicBlocks of the branches the fused kernel takes: one grouped launch per block level (caller's stream)
-    fuse_max_branches = None    # ... at most this many leading branches; None = by batch: 1 below 96 crops, 3 from there (measured end to end, one
-                                # box each: 20 crops none / 1 / 3 -> 3.08 / 3.14 / 3.46 ms; 60 crops 7.77 / 7.91 / 8.23 ms; 217 crops 29.0 / 28.2 / 27.1 ms;
-                                # fused blocks move 16 % less HBM traffic and take 32 launches fewer per forward)
+    fuse_max_branches = None    # ... at most this many leading branches; None = 2: branches 0 and 1 (C = 48 and 96) as ONE grouped launch per block
+                                # level.  Round 3, interleaved A/B on one device (tools/ab_flags.py; 1 / 2 / 3 branches, or no fused block at
+                                # all, against the round-2 rule "1 below 96 crops, 3 from there"): 20 crops 2 -> -1.6 ... -1.9 %, none -0.7 ... -2.2 %,
+                                # 3 -> +8.9 %; 28 crops 2 -> -2.7 %; 60 crops 2 -> +1.0 %, none -1.0 %; 112 crops 2 -> -2.2 %; 217 crops 2 -> -2.3 %
     fuse_waves = 8              # workgroup shape of the fused kernel (8 waves, one workgroup per CU, measured faster than 2 x 4 waves)
     group_fuse = False          # True: fuse layers as one launch per LEVEL of convolutions over all branches + one launch for all sums
                                 # (99 launches per forward instead of 263, but the fuse convolutions no longer run beside the coarse
@@ -660,7 +661,7 @@ class HipHRNet(ConvEngine):
         nb = len(mod['branches'])
         terms = [dict() for _ in fuse]                    # terms[i][j] = (tensor or channel slice, shift, base tensor that carries the event)
         n0 = (xs[0][2] if isinstance(xs[0], tuple) else xs[0]).shape[0]
-        fmax = self.fuse_max_branches if self.fuse_max_branches is not None else (3 if n0 >= 96 else 1)
+        fmax = self.fuse_max_branches if self.fuse_max_branches is not None else 2
         grouped = []
         if self.fuse_blocks:
             for b in range(nb):
@@ -752,7 +753,7 @@ class HipHRNet(ConvEngine):
         grouped = []
         if self.fuse_blocks and xs[0] is not None:
             n0 = (xs[0][2] if isinstance(xs[0], tuple) else xs[0]).shape[0]
-            fmax = self.fuse_max_branches if self.fuse_max_branches is not None else (3 if n0 >= 96 else 1)
+            fmax = self.fuse_max_branches if self.fuse_max_branches is not None else 2
             for b in range(len(mod['branches'])):
                 shp = xs[b][2].shape if isinstance(xs[b], tuple) else xs[b].shape
                 cb = mod['branches'][b][0][0].cin
