@@ -38,10 +38,10 @@ for v in args.variants:
         with torch.cuda.stream(s):
             with torch.cuda.graph(g, stream=s):
                 out = hip.features(x)
-        runs.append((name, g.replay, net, g))
+        runs.append((name, g.replay, net, (g, x, out)))          # keep the static input / output alive: the graph reads / writes them
     else:
         plan = hip.make_plan(x)
-        runs.append((name, (lambda p=plan, m=int(form[-1]): p.replay(m)), net, plan))
+        runs.append((name, (lambda p=plan, m=int(form[-1]): p.replay(m)), net, (plan, x)))
 for _, run, _, _ in runs:
     for _ in range(5): run()
 torch.cuda.synchronize()
