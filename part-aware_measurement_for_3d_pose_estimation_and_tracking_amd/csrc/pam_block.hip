@@ -53,6 +53,14 @@ extern "C" int pam_block_debug_stamps(void* dev_buf) { g_bb_stamps = (unsigned l
 #define BB_STAMP(k) do { } while (0)
 #endif
 #define BB_WAITVM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+// barrier between conv1 and conv2 of an item.  __syncthreads() also waits vmcnt(0), i.e. drains the weight DMAs of conv2's first chunks;
+// a raw s_barrier behind lgkmcnt(0) keeps them in flight -- measured identical (21.9 vs 21.6 us per C = 48 block, 2.55-2.60 ms per forward
+// either way; tools/ab_build.sh PAM_BB_RAWBARRIER), so the plain form stays
+#ifdef PAM_BB_RAWBARRIER
+#define BB_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); asm volatile("s_barrier" ::: "memory"); } while (0)
+#else
+#define BB_BARRIER() __syncthreads()
+#endif
 #define BB_LGKM0 0xC07F                                  // s_waitcnt immediate: lgkmcnt(0), vmcnt / expcnt untouched
 
 namespace {
@@ -297,7 +305,7 @@ __device__ __forceinline__ void bblock_item(const BBranch& a, int v, char* smem)
 #pragma unroll
             for (int h = 0; h < 3; ++h) { const u32x2 q2 = *(const u32x2*)(p + 8 * h); rres[i][2 * h] = q2[0]; rres[i][2 * h + 1] = q2[1]; }
         }
-        __syncthreads();                                                 // every wave is done reading X
+        BB_BARRIER();                                                    // every wave is done reading X
         // intermediate = ReLU(conv1 + b1) as bf16 at slot p + 1; zero where the grid position is padding / outside the image
 #pragma unroll
         for (int i = 0; i < MW1; ++i) {
@@ -327,7 +335,7 @@ __device__ __forceinline__ void bblock_item(const BBranch& a, int v, char* smem)
         }
         if (tid < PA / 16) *(u32x4*)(Xb + tid * 16) = (u32x4){0, 0, 0, 0};      // slot 0 = the padding column left of the first row
     }
-    __syncthreads();                                    // the intermediate is visible (drains the weight DMAs in flight once per item)
+    BB_BARRIER();                                       // the intermediate is visible
     BB_STAMP(3);
 
     // ---- conv2 + epilogue ----------------------------------------------------------------------------------------------------
