@@ -432,3 +432,46 @@ def test_dependency_schedule_matches_joined_schedule(n):
         assert torch.equal(ref, y)
     c = hrnet.HRNetPose(48, 17, None, use_graph=False)
     assert torch.equal(ref, c.features(x))
+
+
+def test_full_pipeline_panoptic31_sized_frame():
+    """Config #5's frame on ONE GPU through the drop-in surface: 31 HD views x 7 persons = 217 crops -> PersonPoseDetect (eleven batches
+    of 20 through the replay, the last padded) -> PersonTrack_Project3DPose on the device-resident keypoints (k_frame<1024>: more than 8
+    views).  Random weights: the keypoints mean nothing, so what is checked is the plumbing at full size -- every crop decoded into its
+    (view, slot), keypoints inside their boxes, the device fast path taken, a clean tracker status, and the same dump from a second
+    call."""
+    from pam import hrnet, synth
+    from pam.ivclabpose import ivclabpose
+    seq = synth.make_sequence('S4', n_frames=2, seed=0)
+    cfg = dict(synth.MATCHER_CFG[synth.SIZE_TO_DATASET['S4']]); conf = cfg.pop('CONF_THRESHOLD')
+    model = ivclabpose({'NAME': ''}, None, dict(cfg, NAME='Iterative'), conf, max_dets=8, max_tracks=16)
+    model.GetCameraParameters(seq['calib'], 1920, 1080)
+    model.pose_model = hrnet.HRNetPose(48, 17, None, resolution=(384, 288), use_graph=True, max_dets=8)
+    dev = model.pose_model.device
+    g = torch.Generator().manual_seed(3)
+    base = torch.randint(0, 256, (1080, 1920, 3), dtype=torch.uint8, generator=g).to(dev)
+    frames = [torch.roll(base, shifts=17 * v, dims=1).contiguous() for v in range(31)]
+    rng = np.random.default_rng(5)
+    pbl = []
+    for v in range(31):
+        persons = []
+        for p in range(7):
+            w, h = rng.uniform(100, 300), rng.uniform(250, 600)
+            x0, y0 = rng.uniform(0, 1920 - w), rng.uniform(0, 1080 - h)
+            persons.append(dict(image_id=0, category_id=1, score=0.9, bbox=[float(x0), float(y0), float(w), float(h)], data=frames[v], feature=[]))
+        pbl.append(persons)
+    dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
+    assert [len(d) for d in dump] == [7] * 31 and tuple(dump.device_det.shape) == (31, 8, 17, 3) and dump.device_valid()
+    assert sorted(k[0] for k in model.pose_model._graphs) == [20]          # 10 x 20 crops + 17 padded to 20
+    for v in range(31):
+        for it in dump[v]:
+            k = np.array(it['keypoints']).reshape(17, 3); b = it['bbox']
+            assert (k[:, 0] >= b[0] - 1e-3).all() and (k[:, 0] <= b[0] + b[2]).all() and (k[:, 1] >= b[1] - 1e-3).all() and (k[:, 1] <= b[1] + b[3]).all()
+    out = model.PersonTrack_Project3DPose(0, pbl, dump, 'SVD')
+    assert len(out) == 9 and model.tracker.last['status'] == 0 and model.tracker.last['status_sticky'] == 0
+    dump2 = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
+    for a, b in zip(dump, dump2):
+        for ia, ib in zip(a, b):
+            assert ia['keypoints'] == ib['keypoints']
+    out2 = model.PersonTrack_Project3DPose(1, pbl, dump2, 'SVD')
+    assert model.tracker.last['status'] == 0 and len(out2) == 9
