@@ -435,43 +435,59 @@ def test_dependency_schedule_matches_joined_schedule(n):
 
 
 def test_full_pipeline_panoptic31_sized_frame():
-    """Config #5's frame on ONE GPU through the drop-in surface: 31 HD views x 7 persons = 217 crops -> PersonPoseDetect (eleven batches
+    """Config #5's frames on ONE GPU through the drop-in surface: 31 HD views x 7 persons = 217 crops -> PersonPoseDetect (eleven batches
     of 20 through the replay, the last padded) -> PersonTrack_Project3DPose on the device-resident keypoints (k_frame<1024>: more than 8
-    views).  Random weights: the keypoints mean nothing, so what is checked is the plumbing at full size -- every crop decoded into its
-    (view, slot), keypoints inside their boxes, the device fast path taken, a clean tracker status, and the same dump from a second
-    call."""
+    views), four frames.  The network has random weights, so -- exactly as bench.py does -- the decoded keypoints are checked
+    for plumbing (every crop in its (view, slot), inside its box, stable across calls) and then REPLACED on the device by the seeded
+    synthetic ones; the tracker's output on them must equal the oracle's (ids, 3D <= 1e-6 m)."""
     from pam import hrnet, synth
     from pam.ivclabpose import ivclabpose
-    seq = synth.make_sequence('S4', n_frames=2, seed=0)
+    from oracle import cpu_ref as O
+    nf = 4
+    seq = synth.make_sequence('S4', n_frames=nf, seed=0)
     cfg = dict(synth.MATCHER_CFG[synth.SIZE_TO_DATASET['S4']]); conf = cfg.pop('CONF_THRESHOLD')
     model = ivclabpose({'NAME': ''}, None, dict(cfg, NAME='Iterative'), conf, max_dets=8, max_tracks=16)
-    model.GetCameraParameters(seq['calib'], 1920, 1080)
+    cams = model.GetCameraParameters(seq['calib'], 1920, 1080)
+    ref = O.OracleIvclabpose(cfg, conf)
+    ref.GetCameraParameters(seq['calib'], F=np.stack([c.F for c in cams]))
     model.pose_model = hrnet.HRNetPose(48, 17, None, resolution=(384, 288), use_graph=True, max_dets=8)
     dev = model.pose_model.device
     g = torch.Generator().manual_seed(3)
     base = torch.randint(0, 256, (1080, 1920, 3), dtype=torch.uint8, generator=g).to(dev)
     frames = [torch.roll(base, shifts=17 * v, dims=1).contiguous() for v in range(31)]
-    rng = np.random.default_rng(5)
-    pbl = []
-    for v in range(31):
-        persons = []
-        for p in range(7):
-            w, h = rng.uniform(100, 300), rng.uniform(250, 600)
-            x0, y0 = rng.uniform(0, 1920 - w), rng.uniform(0, 1080 - h)
-            persons.append(dict(image_id=0, category_id=1, score=0.9, bbox=[float(x0), float(y0), float(w), float(h)], data=frames[v], feature=[]))
-        pbl.append(persons)
-    dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
-    assert [len(d) for d in dump] == [7] * 31 and tuple(dump.device_det.shape) == (31, 8, 17, 3) and dump.device_valid()
-    assert sorted(k[0] for k in model.pose_model._graphs) == [20]          # 10 x 20 crops + 17 padded to 20
-    for v in range(31):
-        for it in dump[v]:
-            k = np.array(it['keypoints']).reshape(17, 3); b = it['bbox']
-            assert (k[:, 0] >= b[0] - 1e-3).all() and (k[:, 0] <= b[0] + b[2]).all() and (k[:, 1] >= b[1] - 1e-3).all() and (k[:, 1] <= b[1] + b[3]).all()
-    out = model.PersonTrack_Project3DPose(0, pbl, dump, 'SVD')
-    assert len(out) == 9 and model.tracker.last['status'] == 0 and model.tracker.last['status_sticky'] == 0
-    dump2 = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
-    for a, b in zip(dump, dump2):
-        for ia, ib in zip(a, b):
-            assert ia['keypoints'] == ib['keypoints']
-    out2 = model.PersonTrack_Project3DPose(1, pbl, dump2, 'SVD')
-    assert model.tracker.last['status'] == 0 and len(out2) == 9
+    n_det_all, det_all = synth.pack_frames(seq['frames'], 8)
+    emitted = 0
+    for t in range(nf):
+        pbl = []
+        for v in range(31):
+            persons = []
+            for kp in seq['frames'][t][v]:
+                x0, y0, x1, y1 = kp[:, 0].min(), kp[:, 1].min(), kp[:, 0].max(), kp[:, 1].max()
+                persons.append(dict(image_id=t, category_id=1, score=0.9, data=frames[v], feature=[],
+                                    bbox=[float(x0 - 0.125 * (x1 - x0)), float(y0 - 0.125 * (y1 - y0)), float(1.25 * (x1 - x0)), float(1.25 * (y1 - y0))]))
+            pbl.append(persons)
+        dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
+        assert [len(d) for d in dump] == [int(n) for n in n_det_all[t]] and sum(len(d) for d in dump) == 217
+        assert tuple(dump.device_det.shape) == (31, 8, 17, 3) and dump.device_valid()
+        assert sorted(k[0] for k in model.pose_model._graphs) == [20]          # 10 x 20 crops + 17 padded to 20
+        if t == 0:
+            for v in range(31):
+                for it in dump[v]:
+                    k = np.array(it['keypoints']).reshape(17, 3); b = it['bbox']
+                    assert (k[:, 0] >= b[0] - 1e-2).all() and (k[:, 0] <= b[0] + b[2] + 1e-2).all()
+                    assert (k[:, 1] >= b[1] - 1e-2).all() and (k[:, 1] <= b[1] + b[3] + 1e-2).all()
+            dump2 = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
+            for a_, b_ in zip(dump, dump2):
+                for ia, ib in zip(a_, b_):
+                    assert ia['keypoints'] == ib['keypoints']
+        dump.device_det.copy_(torch.tensor(det_all[t], dtype=torch.float64, device=dev))          # synthetic keypoints instead of the random net's
+        dump.poses_host = [det_all[t][v][:n_det_all[t][v]] for v in range(31)]
+        out = model.PersonTrack_Project3DPose(t, pbl, dump, 'SVD')
+        assert model.tracker.last['status'] == 0 and model.tracker.last['status_sticky'] == 0
+        pbl_o, dr_o = synth.to_dump_results(seq['frames'][t])
+        exp = ref.PersonTrack_Project3DPose(t, pbl_o, dr_o, 'SVD')
+        assert list(out[5]) == list(exp[5])
+        if len(out[5]):
+            assert np.abs(np.asarray(out[3]) - np.asarray(exp[3])).max() < 1e-6
+            emitted += len(out[5])
+    assert emitted >= 7
