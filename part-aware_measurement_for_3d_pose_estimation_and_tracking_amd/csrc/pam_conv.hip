@@ -835,14 +835,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
         }
     }
     // LDS byte offsets (inside a chunk buffer) of this lane's patch fragment for M tile i and tap t, swizzle included
-    unsigned aoff[MT][9];
+    // M tile i sits 16 slots = 1024 bytes behind tile 0 and has the same swizzle (it depends on bit 2 of the slot only): nine offsets
+    // + immediates instead of MT x 9 registers
+    unsigned aoff0[9];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int s = wave * 16 * MT + i * 16 + (lane & 15) + (t / 3) * PW + (t % 3);
-            aoff[i][t] = (unsigned)(s * 64 + ((g ^ ((s >> 1) & 2)) << 4));
-        }
+    for (int t = 0; t < 9; ++t) {
+        const int s = wave * 16 * MT + (lane & 15) + (t / 3) * PW + (t % 3);
+        aoff0[t] = (unsigned)(s * 64 + ((g ^ ((s >> 1) & 2)) << 4));
+    }
     const unsigned woff = (unsigned)(PIMG + (lane & 15) * 64 + ((g ^ ((lane >> 1) & 2)) << 4));   // row j*16 + (lane & 15): bit 2 of the row = bit 2 of the lane
 
     // One software pipeline over all NCHUNK * 9 k-steps: the fragments of step s + 1 are read while the MFMAs of step s issue, and a
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) bf_[j] = *(const bf16x8*)(buf + woff + (t * BN + j * 16) * 64);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af_[i] = *(const bf16x8*)(buf + aoff[i][t]);
+        for (int i = 0; i < MT; ++i) af_[i] = *(const bf16x8*)(buf + aoff0[t] + i * 1024);
     };
     auto chunk = [&](int k, auto PARC) {
         constexpr int PAR = decltype(PARC)::value;
@@ -928,7 +928,15 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
     static const int mask = getenv("PAM_C3S_MASK") ? atoi(getenv("PAM_C3S_MASK")) : 14;      // tuning hook: 2 = Cin 192, 4 = 384, 8 = 64 / 256
     if (!(mask & (Cin == 192 ? 2 : (Cin == 384 ? 4 : 8)))) return false;
 #endif
-    const int PW = W + 2, smax = 320, pcap = l1 ? 448 : 384;
+    // 8 M tiles per wave / 576 patch slots = a whole 24 x 18 image per workgroup (half the workgroups, weights streamed once per image):
+    // measured 24.3 vs 11.2 us per convolution (256 VGPRs, 31 spilled) and 3.03-3.07 vs 2.65-2.68 ms per 20-crop forward -- the 192-channel
+    // chain becomes the module's critical path.  Off; -DPAM_C3S_TALL builds it (tools/ab_build.sh).
+#ifdef PAM_C3S_TALL
+    const bool tall = Cin == 192;
+#else
+    const bool tall = false;
+#endif
+    const int PW = W + 2, smax = tall ? 512 : 320, pcap = l1 ? 448 : (tall ? 576 : 384);
     // rows per tile: the height that costs the fewest M tiles over the image (a tile always multiplies whole 64-slot wave shares, 3 to
     // 5 of them, and a ragged last tile multiplies as much as a full one); ties go to the taller tile = fewer workgroups
     TH = 0; mt = 0; pmax = 0;
@@ -937,9 +945,10 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
         const int sl = t * PW, np = (t + 2) * PW;
         if (np > pcap) continue;
         // the instantiated (M tiles per wave, patch slots) shapes: (3, 192), (4, 320), (5, 384 | 448) -- the smallest that holds the tile
-        const int m = (sl <= 192 && np <= 192) ? 3 : ((sl <= 256 && np <= 320) ? 4 : 5);
+        const int m = (sl <= 192 && np <= 192) ? 3 : ((sl <= 256 && np <= 320) ? 4 : ((sl <= 320 && np <= 448) ? 5 : 8));
+        if (m == 8 && !tall) continue;
         const long cost = (long)((H + t - 1) / t) * m;
-        if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : (np <= 384 ? 384 : 448)); }
+        if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : (m == 8 ? 576 : (np <= 384 ? 384 : 448))); }
     }
     if (TH < 1) return false;
     const int bn = Cout == 48 ? 48 : 64;
@@ -986,6 +995,7 @@ static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, 
     }
     if (pmax == 448) return PAM_E_ARG;
     switch (Cin * 100 + ntw * 10 + mt) {
+        case 19248: return launch_c3s_one<192, 4, 8, 576, 2>(s, a);
         case 19243: return launch_c3s_one<192, 4, 3, 192, 3>(s, a);
         case 19244: return launch_c3s_one<192, 4, 4, 320, 2>(s, a);
         case 19245: return launch_c3s_one<192, 4, 5, 384, 2>(s, a);
