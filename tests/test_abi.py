@@ -79,3 +79,19 @@ def test_hrnet_definition():
               'final_layer.bias'):
         assert k in keys, k
     assert not any(k.startswith('stage4.2.fuse_layers.1') for k in keys)
+
+
+def test_bench_counts_gpus_without_touching_hip(monkeypatch):
+    """bench.py's self-launching parent must learn the device count from the environment / KFD topology, never from HIP."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1,2')
+    assert b.visible_gpu_count() == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '')
+    assert b.visible_gpu_count() == 0
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False); monkeypatch.delenv('CUDA_VISIBLE_DEVICES', raising=False)
+    assert b.visible_gpu_count() >= 0                   # no KFD here: falls back without raising
+    assert b.algorithmic_bytes_per_frame(5, 4, 4, 5, 11) == 39520      # SURVEY 8d's Shelf figure
