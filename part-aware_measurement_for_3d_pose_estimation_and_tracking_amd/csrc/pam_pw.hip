@@ -316,12 +316,12 @@ extern "C" int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const
     a.w1 = (const uint16_t*)w1_img; a.b1 = bias1; a.outx = (uint16_t*)out_x; a.outy = (uint16_t*)out_y1; a.M = (int)n_pixels;
     hipStream_t s = (hipStream_t)stream;
     const int S = x0 ? 2 : 1, has2 = w1_img ? 1 : 0, res = residual ? 1 : 0;
-    // tile_cfg = MT + 10 * (16 waves per workgroup instead of 8): MT = 16-pixel tiles per wave tile (1, 2 or 3); <= 0 = automatic.
+    // tile_cfg = MT + 10 * (1: 16 waves per workgroup instead of 8; 2: two 8-wave workgroups per CU): MT = 16-pixel tiles per wave tile (1, 2 or 3); <= 0 = automatic.
     // Purely a latency-hiding choice (the waves are independent): measured at 20 crops, 96 x 72: MT = 1 34 us, 2 44 us, 3 42 us with 8 waves
     const int cfg = tile_cfg > 0 ? tile_cfg : 1;
-    const int mt = cfg % 10, nw16 = cfg / 10;
-    if (mt < 1 || mt > 3 || nw16 > 1 || (nw16 && mt != 1)) return PAM_E_ARG;
-    const int max_wg = 256;
+    const int mt = cfg % 10, nw16 = cfg / 10 == 1;
+    if (mt < 1 || mt > 3 || cfg / 10 > 2 || (cfg / 10 && mt != 1)) return PAM_E_ARG;
+    const int max_wg = cfg / 10 == 2 ? 512 : 256;        // 21: two 8-wave workgroups per CU (124 VGPRs, 64 KB of LDS each)
 #define PW_CASE(S_, R_, H_) \
     if (S == S_ && res == R_ && has2 == H_) { \
         if (nw16) return launch_pw2<S_, R_ != 0, H_ != 0, 1, 16>(s, a, max_wg); \
