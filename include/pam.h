@@ -221,6 +221,11 @@ int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
  * 256 -> 48); the streamed kernel takes activation codes 0 / 1 only, so a layer with a Darknet code (relu > 1) must be packed in the
  * classic layout and called with tile_cfg == -2 (tile_cfg == -1 with a streamed image and relu > 1 returns PAM_E_ARG). */
 int pam_conv3x3_layout(int H, int W, int Cin, int Cout);
+/* run-time options of the convolution entry point, for experiments that must be switchable inside one process; returns the previous
+ * value.  PAM_CONV_OPT_C96_STREAMED: 96 -> 96 3x3 stride-1 layers on the streamed kernel with 48-channel slabs (pam_conv3x3_layout()
+ * then announces the streamed image for them; set it before the layer's weight image is packed). */
+#define PAM_CONV_OPT_C96_STREAMED 1
+int pam_conv_option(int key, int value);
 /* which kernel the calling thread's last pam_conv2d_nhwc_bf16[_ex] call launched (labels for per-kernel profiles) */
 #define PAM_CONV_KERNEL_IGEMM 0   /* k_conv_igemm */
 #define PAM_CONV_KERNEL_3X3   1   /* k_conv3x3   */

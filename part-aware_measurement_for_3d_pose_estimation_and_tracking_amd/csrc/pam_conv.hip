@@ -919,11 +919,20 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
 // (LDS ring): the tile is the tallest whole-row tile that fits (a divisor of H when that costs < 15 %).
 // Cin 96 stays on k_conv3x3: its streamed form (96-channel slabs, 160 workgroups) is as fast alone (12.9 vs 13.0 us) but 3-5 % slower
 // end to end -- a 150 KB workgroup shuts the other branches out of its CU, and the 48 x 36 layers have enough tiles to fill the chip.
+// run-time options of the convolution entry point (pam_conv_option): experiments that must be switchable inside one process
+static int g_conv_opt[8] = {0};
+extern "C" int pam_conv_option(int key, int value) {
+    if (key < 0 || key >= 8) return PAM_E_ARG;
+    const int old = g_conv_opt[key];
+    g_conv_opt[key] = value;
+    return old;
+}
 static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax, int& ntw) {
     // layer1 / transition1 of HRNet (64 -> 64 and 256 -> 48 at 96 x 72: ReLU layers; the detector's 64- and 256-channel 3x3 layers have
     // other widths and a leaky activation and stay on k_conv3x3): two rounds of 480 workgroups, still 24 -> 16 us and 59 -> 30 us
     const bool l1 = (Cin == 64 && Cout == 64) || (Cin == 256 && Cout == 48);
-    if (Cin != 192 && Cin != 384 && !l1) return false;
+    const bool c96 = Cin == 96 && Cout == 96 && g_conv_opt[PAM_CONV_OPT_C96_STREAMED] != 0;      // 48-channel slabs, two-slot ring
+    if (Cin != 192 && Cin != 384 && !l1 && !c96) return false;
 #ifdef PAM_DIAG
     static const int mask = getenv("PAM_C3S_MASK") ? atoi(getenv("PAM_C3S_MASK")) : 14;      // tuning hook: 2 = Cin 192, 4 = 384, 8 = 64 / 256
     if (!(mask & (Cin == 192 ? 2 : (Cin == 384 ? 4 : 8)))) return false;
@@ -951,9 +960,10 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
         if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : (m == 8 ? 576 : (np <= 384 ? 384 : 448))); }
     }
     if (TH < 1) return false;
-    const int bn = Cout == 48 ? 48 : 64;
+    const int bn = (Cout == 48 || c96) ? 48 : 64;
     if (Cout % bn != 0) return false;
     ntw = bn / 16;
+    if (c96) return true;
     // only shapes launch_c3s() instantiates: 64-channel slabs for Cin 192 / 384 (and 64 -> 64), the 48-channel slab for 256 -> 48;
     // anything else (e.g. Cin 192 -> Cout 48) stays on k_conv3x3 / the implicit GEMM and keeps the classic weight image
     if (Cin == 256 ? ntw != 3 : ntw != 4) return false;
@@ -995,6 +1005,9 @@ static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, 
     }
     if (pmax == 448) return PAM_E_ARG;
     switch (Cin * 100 + ntw * 10 + mt) {
+        case 9633: return launch_c3s_one<96, 3, 3, 192, 2>(s, a);
+        case 9634: return launch_c3s_one<96, 3, 4, 320, 2>(s, a);
+        case 9635: return launch_c3s_one<96, 3, 5, 384, 2>(s, a);
         case 19248: return launch_c3s_one<192, 4, 8, 576, 2>(s, a);
         case 19243: return launch_c3s_one<192, 4, 3, 192, 3>(s, a);
         case 19244: return launch_c3s_one<192, 4, 4, 320, 2>(s, a);

@@ -203,3 +203,34 @@ def test_leaky_layer_of_a_streamed_shape_takes_the_classic_kernel():
     assert bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all()), float(err.max())
     y2 = e.conv(op, x, relu=True)
     assert e.lib.pam_conv_last_kernel() == 2                           # k_conv3x3s
+
+
+@pytest.mark.parametrize('shape', [(20, 48, 36), (2, 25, 18), (3, 7, 5), (2, 50, 30)])
+def test_streamed_kernel_for_the_96_channel_branch_behind_its_option(eng, shape):
+    """pam_conv_option(PAM_CONV_OPT_C96_STREAMED): 96 -> 96 3x3 layers on k_conv3x3s with 48-channel slabs (off by default) vs torch fp32."""
+    from pam import _lib, hrnet_hip
+    n, h, w = shape
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    conv = nn.Conv2d(96, 96, 3, 1, 1, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (96 * 9)) ** 0.5)
+        conv.bias.copy_(torch.randn(96, generator=g))
+    x = torch.randn((n, 96, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    res = torch.randn((n, 96, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
+    e.lib = lib; e.device = dev; e.tile_cfg = -1
+    assert lib.pam_conv3x3_layout(h, w, 96, 96) == 0
+    old = lib.pam_conv_option(1, 1)
+    try:
+        assert lib.pam_conv3x3_layout(h, w, 96, 96) == 48
+        op = hrnet_hip.PackedConv(conv, dev)
+        y = e.conv(op, x, res=res, relu=True)
+        assert lib.pam_conv_last_kernel() == 2            # PAM_CONV_KERNEL_3X3S
+    finally:
+        lib.pam_conv_option(1, old)
+    ref = torch.relu(F.conv2d(x.float(), conv.weight.detach().to(torch.bfloat16).float().to(dev), conv.bias.detach().to(dev), 1, 1) + res.float())
+    torch.cuda.synchronize()
+    err = (y.float() - ref).abs()
+    assert bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all()), float(err.max())

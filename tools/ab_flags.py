@@ -19,10 +19,13 @@ for v in args.variants:
     hip = net.hip
     hip.dag = False
     form = 'graph'
+    opts = []
     for kv in [q for q in spec.split(',') if q]:
         k, _, val = kv.partition('=')
         if k == 'form':
             form = val
+        elif k.startswith('opt'):                        # library option, e.g. opt1=1 (PAM_CONV_OPT_C96_STREAMED); reset after the capture
+            hip.lib.pam_conv_option(int(k[3:]), int(val)); opts.append(int(k[3:]))
         else:
             cur = getattr(hip, k)
             if isinstance(cur, tuple):
@@ -42,6 +45,8 @@ for v in args.variants:
     else:
         plan = hip.make_plan(x)
         runs.append((name, (lambda p=plan, m=int(form[-1]): p.replay(m)), net, (plan, x)))
+    for o in opts:
+        hip.lib.pam_conv_option(o, 0)
 for _, run, _, _ in runs:
     for _ in range(5): run()
 torch.cuda.synchronize()
