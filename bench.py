@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument('--no-extra', action='store_true', help='N > 1: skip the crop-balanced run and the single-GPU run of the same workload')
     ap.add_argument('--batched-scenes', type=int, default=2048)
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-autotune', action='store_true', help="keep the conv stack in the executor's default configuration instead of the fastest per crop count")
     ap.add_argument('--pose-streams', type=int, default=1, choices=[1, 2], help='2: the forwards of consecutive frames alternate between two streams / replay slots and overlap')
     ap.add_argument('--no-overlap', action='store_true', help='run the tracker of frame t on the pose stream instead of under frame t+1')
     return ap.parse_args()
@@ -406,7 +407,7 @@ def main():
     pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
                          rank=rank, use_graph=not args.no_graph, shard=shard, overlap_tracker=overlap,
                          exchange=args.exchange if (shard == 'views' and not single_dev) else 'torch',
-                         pose_streams=args.pose_streams if overlap else 1)
+                         pose_streams=args.pose_streams if overlap else 1, autotune=not args.no_autotune)
     inp = build_inputs(torch, synth, seq, size, max_dets, world, rank, shard, dev, nF)
     torch.cuda.synchronize()
 
@@ -438,7 +439,10 @@ def main():
     work = {}
     for n in sorted(set(local_crops[W:])):
         if n > 0:
-            work[n] = hrnet_mod.algorithmic_work(n)
+            cfgname = 'grouped'
+            if pipe.net is not None and pipe.net.backend == 'hip':
+                cfgname = pipe.net.tuned[n]['choice'] if (pipe.net.autotune and n in pipe.net.tuned) else pipe.net.hip.config_name
+            work[n] = hrnet_mod.algorithmic_work(n, config=cfgname)
     hr_ms = [a.elapsed_time(b) for (a, b), n in zip(evs, local_crops[W:]) if n > 0]
     hr_fl = [work[n]['flops'] for n in local_crops[W:] if n > 0]
     hr_by = [work[n]['bytes'] for n in local_crops[W:] if n > 0]
@@ -472,6 +476,8 @@ def main():
                        'views_per_rank': [len(p) for p in view_partition(C, world)] if shard == 'views' else None,
                        'tracker': 'fused HIP frame kernel (f64), replicated after the exchange', 'hrnet_weights': pipe.net.weights if pipe.net else None,
                        'conv_backend': pipe.net.backend if pipe.net else None,
+                       'conv_executor': ({str(n): t for n, t in pipe.net.tuned.items()} if pipe.net is not None and pipe.net.autotune else
+                                         (pipe.net.hip.config_name if pipe.net is not None and pipe.net.backend == 'hip' else None)),
                        'exchange': ('one all-gather per frame (%s)' % ('pam_allgather_keypoints: RCCL called inside the C ABI' if pipe.comm else 'torch.distributed ' + backend)) if world > 1 else 'none',
                        'devices': '%d ranks on ONE device (no multi-GPU box: functional check only)' % world if single_dev and world > 1 else '%d' % world},
             'roofline': {'kernel': 'HRNet-W48 conv stack: k_bblock / k_conv3x3[s] / k_conv_gs / k_conv_igemm / k_pw1 / k_pw2 / k_upsample_add (hipGraph replay, %d crops, %d launches)'

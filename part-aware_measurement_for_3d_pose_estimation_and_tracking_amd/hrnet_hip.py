@@ -587,6 +587,23 @@ class HipHRNet(ConvEngine):
     # waits are plain edges.  (All side streams are forked from the caller's stream at the start of the forward and joined at its end.)
     dag = False                 # measured: 2.68 ms (plan, eager replay) vs 2.61 ms (one join per module, captured hipGraph) at 20 crops, same box
 
+    # Executor configurations the replay autotuner chooses between per crop count (HRNetPose(autotune=True)): which of them is fastest
+    # depends on how a crop count's tile counts quantise on 256 CUs -- interleaved A/B, one device, vs 'grouped': 20 crops 'streamed96'
+    # -2.8 %, 'unfused' -0.4 %; 28 crops 0 / +1.1 %; 40 crops +2.2 / +1.3 %; 60 crops -0.6 / -2.9 %; 112 crops +4.1 %; 217 crops +6.6 %.
+    CONFIGS = {
+        'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0),      # branches 0 + 1 as one fused-BasicBlock launch per level
+        'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=0),     # one launch per convolution, 96-channel branch on k_conv3x3
+        'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=1),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
+    }
+    c96_streamed = 0            # PAM_CONV_OPT_C96_STREAMED while THIS executor issues / captures a forward (a library-wide switch)
+
+    def apply_config(self, name):
+        for k, v in self.CONFIGS[name].items():
+            setattr(self, k, v)
+        self.config_name = name
+
+    config_name = 'grouped'
+
     plan_rec = False            # True while a launch plan is being recorded (make_plan): stream switches, event records and waits go to
                                 # pam_plan_* instead of torch streams / events, launches are stored by the library instead of issued
 
@@ -897,7 +914,13 @@ class HipHRNet(ConvEngine):
         """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
         self._keep = []
         self._evt = {}
-        return self._features(x8)
+        if not self.c96_streamed:
+            return self._features(x8)
+        old = self.lib.pam_conv_option(1, 1)              # PAM_CONV_OPT_C96_STREAMED: decided at launch (and capture) time
+        try:
+            return self._features(x8)
+        finally:
+            self.lib.pam_conv_option(1, old)
 
     fuse_tail = True            # layer1: conv3 + residual + next conv1 of every Bottleneck in one launch (csrc/pam_pw.hip)
     tail_cfg = 0                # its wave-tile size (0 = automatic)

@@ -67,7 +67,9 @@ def fundamental_matrices(K, RT):
 
 class ivclabpose(object):
     def __init__(self, person_detector=None, pose_detector=None, person_matcher=None, conf_threshold=0.4,
-                 max_dets=16, max_tracks=32, device=0):
+                 max_dets=16, max_tracks=32, device=0, autotune=False):
+        """autotune (not in the reference): let the pose network pick the fastest of its executor configurations per crop count on this
+        device (HRNetPose(autotune=True)); off by default because two batchings of the same crops may then differ in the last bf16 bits."""
         self.person_detector = person_detector if _cfg(person_detector, 'NAME') != '' else None
         self.pose_detector = pose_detector
         self.person_matcher = person_matcher
@@ -104,7 +106,8 @@ class ivclabpose(object):
                                         model_name=_cfg(self.pose_detector, 'MODEL_NAME'),
                                         resolution=tuple(_cfg(self.pose_detector, 'RESOLUTION')), hrpose_args=gpu_args,
                                         device=device, max_dets=max_dets,
-                                        shard_crops=torch.distributed.is_available() and torch.distributed.is_initialized())
+                                        shard_crops=torch.distributed.is_available() and torch.distributed.is_initialized(),
+                                        autotune=autotune)
             # optional key (not in the reference's YAMLs): SOFT_ARGMAX_BETA > 0 switches the decode from the hard arg-max (parity mode)
             # to the soft-arg-max of pam_head_decode_soft with that inverse temperature
             sb = self.pose_detector.get('SOFT_ARGMAX_BETA') if isinstance(self.pose_detector, dict) else getattr(self.pose_detector, 'SOFT_ARGMAX_BETA', None)

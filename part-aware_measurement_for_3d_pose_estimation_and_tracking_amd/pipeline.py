@@ -19,14 +19,16 @@ NUM_JOINTS = 17
 class FramePipeline(object):
     def __init__(self, calib_cameras, matcher, conf_threshold, frame_hw, max_dets=8, max_tracks=16, device=0, world=1,
                  rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False, net=None, exchange='torch',
-                 pose_streams=1):
+                 pose_streams=1, autotune=True):
         """shard: 'views' -- rank owns whole camera views (pose_step / track_step take view-local inputs); 'crops' -- the
         frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices).
         overlap_tracker (either mode): exchange + tracker kernel + fetch of frame t run on their own stream, under the conv
         stack of frame t+1 (the tracker is one workgroup per scene; it rides on CUs the conv kernels leave idle).
         pose_streams = 2: the crop -> conv stack -> decode chains of consecutive frames alternate between two streams, each with its own
         replay instance (static input, activations, output) of the same weights, so frame t+1's HBM-bound stem / layer1 runs beside
-        frame t's CU-bound last stages.  Frames still finish in order (the tracker stream takes them in order)."""
+        frame t's CU-bound last stages.  Frames still finish in order (the tracker stream takes them in order).
+        autotune: the conv stack's replay of every crop count is the fastest of the executor's configurations on this device
+        (HRNetPose(autotune=True))."""
         self.device = torch.device('cuda:%d' % device)
         torch.cuda.set_device(self.device)
         self.cams = calib_cameras
@@ -40,7 +42,7 @@ class FramePipeline(object):
                                 np.stack([c.RK_INV for c in calib_cameras]), np.stack([c.position for c in calib_cameras]))
         # net: an existing HRNetPose to share (weights, packed images, captured graphs) between several pipelines of one process
         self.net = net if net is not None else (HRNetPose(48, 17, None, resolution=(384, 288), device=device, use_graph=use_graph, seed=seed,
-                                                          max_dets=max_dets) if hrnet else None)
+                                                          max_dets=max_dets, autotune=autotune) if hrnet else None)
         self.shard = shard
         # exchange: 'torch' = torch.distributed (RCCL when the backend is nccl, gloo in the CPU tests); 'abi' = pam_allgather_keypoints,
         # the library's own RCCL call on the decode stream (view sharding only)

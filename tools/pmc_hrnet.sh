@@ -1,11 +1,11 @@
 #!/bin/bash
 # HBM traffic of one HRNet forward (20 crops) from rocprofv3 PMC counters: separate passes for FETCH_SIZE and WRITE_SIZE.
 # usage (on the GPU box, through gpurun): tools/pmc_hrnet.sh <git commit of the build> [round tag]
-COMMIT=${1:-unknown}; TAG=${2:-r03}
+COMMIT=${1:-unknown}; TAG=${2:-r03}; CONFIG=${3:-grouped}       # CONFIG: the executor configuration bench.py's autotuner chose for 20 crops
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_hrnet; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 for P in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $P --output-format csv -d $OUT/$P -- python3 $GRAFT_REPO_ROOT/tools/bench_hrnet.py --backends hip --modes eager --iters 2 > /dev/null 2>&1
+  rocprofv3 --pmc $P --output-format csv -d $OUT/$P -- python3 $GRAFT_REPO_ROOT/tools/bench_hrnet.py --backends hip --modes eager --iters 2 --config $CONFIG > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, glob, json, os
@@ -19,7 +19,7 @@ for P in ('FETCH_SIZE','WRITE_SIZE'):
     res[P]={'sum_kb':tot,'forwards':nfw,'kb_per_forward':tot/nfw,'kernels_per_forward':len(conv)/nfw}
 # guide: FETCH_SIZE (KB) reads exactly half of a wide coalesced stream on gfx950 -> double it; WRITE_SIZE is exact
 res['hbm_bytes_per_forward']=(2*res['FETCH_SIZE']['kb_per_forward']+res['WRITE_SIZE']['kb_per_forward'])*1024
-res['git_commit']='$COMMIT'; res['crops']=20; res['launches_per_forward']=res['FETCH_SIZE']['kernels_per_forward']
+res['git_commit']='$COMMIT'; res['crops']=20; res['executor_config']='$CONFIG'; res['launches_per_forward']=res['FETCH_SIZE']['kernels_per_forward']
 res['note']='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, summed over the k_bblock / k_conv3x3 / k_conv_gs / k_conv_igemm / k_conv_stem / k_pw1 / k_pw2 / k_upsample_add kernels of one 20-crop HRNet-W48 forward (tools/pmc_hrnet.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 reports half of wide coalesced reads), WRITE_SIZE taken as is'
 print(json.dumps(res))
 open('$OUT/${TAG}_hrnet_hbm_traffic.json','w').write(json.dumps(res, indent=1))

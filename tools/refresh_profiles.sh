@@ -4,7 +4,10 @@
 COMMIT=${1:-unknown}; TAG=${2:-r03}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; mkdir -p $OUT
 cd $R
-bash tools/pmc_hrnet.sh $COMMIT $TAG > $OUT/pmc_hrnet.log 2>&1
+# the executor configuration the autotuner picks for 20 crops on THIS box (a short bench run), then the whole-forward HBM counters in it
+CONFIG=$(python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-families --no-surface --no-batched --no-drift --no-pair --no-h2d 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['config']['conv_executor']['20']['choice'])")
+echo "executor configuration for 20 crops: $CONFIG"
+bash tools/pmc_hrnet.sh $COMMIT $TAG ${CONFIG:-grouped} > $OUT/pmc_hrnet.log 2>&1
 cp gpurun_out/pmc_hrnet/${TAG}_hrnet_hbm_traffic.json profiles/ 2>/dev/null       # bench.py stamps roofline.traffic from the newest one
 python3 bench.py > $OUT/${TAG}_bench_S2_n1.json 2> $OUT/bench.err
 ( cd /tmp; export TMPDIR=/tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 30 --warmup 5 > $OUT/${TAG}_bench_S2_under_rocprof.json 2> $OUT/rocprof.err )
