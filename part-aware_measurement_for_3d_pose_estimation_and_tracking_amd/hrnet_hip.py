@@ -594,6 +594,7 @@ class HipHRNet(ConvEngine):
         'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0),      # branches 0 + 1 as one fused-BasicBlock launch per level
         'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=0),     # one launch per convolution, 96-channel branch on k_conv3x3
         'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=1),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
+        'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_streamed=1),   # branch 0 fused alone, branch 1 streamed
     }
     c96_streamed = 0            # PAM_CONV_OPT_C96_STREAMED while THIS executor issues / captures a forward (a library-wide switch)
 

@@ -491,3 +491,25 @@ def test_full_pipeline_panoptic31_sized_frame():
             assert np.abs(np.asarray(out[3]) - np.asarray(exp[3])).max() < 1e-6
             emitted += len(out[5])
     assert emitted >= 7
+
+
+def test_replay_autotune_picks_a_configuration_and_stays_consistent():
+    """HRNetPose(autotune=True): the first replay of a crop count times every executor configuration and keeps the fastest; the result
+    is the same network (equal to the default configuration up to bf16 summation-order noise), replays are deterministic, and a second
+    replay slot of the same crop count reuses the choice."""
+    from pam import hrnet, hrnet_hip
+    a = hrnet.HRNetPose(48, 17, None, use_graph=True)
+    b = hrnet.HRNetPose(48, 17, None, use_graph=True, autotune=True)
+    x = a.input_buffer(3)
+    x.copy_(torch.randn(x.shape, device=x.device).to(x.dtype)); x[:, 3:] = 0
+    ref = a.features(x).float().clone()
+    y1 = b.features(x).clone()
+    y2 = b.features(x).clone()
+    y3 = b.features(x, slot=1).clone()
+    torch.cuda.synchronize()
+    t = b.tuned[3]
+    assert t['choice'] in hrnet_hip.HipHRNet.CONFIGS and set(t['ms']) == set(hrnet_hip.HipHRNet.CONFIGS)
+    assert t['ms'][t['choice']] == min(t['ms'].values())
+    assert torch.equal(y1, y2) and torch.equal(y1, y3)
+    assert float((y1.float() - ref).norm() / ref.norm()) < 1e-2
+    assert b.hip.config_name == t['choice'] and a.hip.config_name == 'grouped' and not a.tuned
