@@ -260,7 +260,9 @@ typedef struct PamBlockDesc {
 int pam_basic_block_rows(int C, int H, int W, int waves);
 int pam_basic_block_chunk_layout(int C, int32_t* out5);
 int pam_basic_block_nhwc_bf16(void* stream, int n_branches, const PamBlockDesc* blocks);
-/* waves: 4 = 256-thread workgroups, two per CU (C = 48 / 96 only), 8 = 512-thread workgroups, 0 = 4 when every branch allows it */
+/* waves: 4 = 256-thread workgroups, two per CU (C = 48 / 96 only), 8 = 512-thread workgroups, 0 = 4 when every branch allows it;
+ * with 8, bits 4-7 are a mask: bit k set = branch k of the call runs as "short" items (4-row tiles with their own M-tile counts: twice
+ * the items at about half the cost each, C = 48 / 96) -- a packing choice for grouped launches, same results */
 int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* blocks, int waves);
 
 /* ---- the pointwise tail of a layer1 Bottleneck as ONE launch (row a1; csrc/pam_pw.hip) ------------------------------------------

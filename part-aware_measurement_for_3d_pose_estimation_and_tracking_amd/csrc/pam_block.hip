@@ -67,7 +67,7 @@ namespace {
 
 struct BBranch {
     const uint16_t* in; const uint16_t* wimg; const float* bias; uint16_t* out;
-    int N, H, W, C, TH, tiles_y, item0, nitems;
+    int N, H, W, C, TH, tiles_y, item0, nitems, sh;
     float inv_pw;
 #ifdef PAM_DIAG
     unsigned long long* stamps;
@@ -76,7 +76,9 @@ struct BBranch {
 struct BBArgs { BBranch br[PAM_BLOCK_MAX_BRANCHES]; int nbr; };
 
 // per-width constants (host and device).  NW = waves per workgroup.
-template <int C, int NW> struct BCfg {
+// SH ("short" items, NW = 8, C = 48 / 96 only): 4-row tiles with their own M-tile counts -- twice the items at roughly half the cost each,
+// for grouped launches whose items would otherwise pack badly on 256 CUs (360 items of 22-29 us = two rounds for 104 of them)
+template <int C, int NW, bool SH = false> struct BCfg {
     static constexpr int NSLAB = C / 48, MPARTS = NW / NSLAB;
     static constexpr int PA = (C == 48) ? 96 : 2 * C + 32;                 // bytes per X slot
     static constexpr int KSTEPS = (9 * C + 31) / 32;                       // 32-deep k-steps that carry weights: K = flattened (tap, cin), zero tail
@@ -91,11 +93,11 @@ template <int C, int NW> struct BCfg {
     static constexpr int CHB = KS * SUB;                                    // bytes per chunk (whole 1-KiB DMA pieces)
     static_assert(CHB % 1024 == 0, "chunk = whole DMA pieces");
     // M tiles per wave, conv1 / conv2
-    static constexpr int MW1 = NW == 8 ? (C == 192 ? 5 : 6) : (C == 48 ? 7 : 6);
-    static constexpr int MW2 = NW == 8 ? (C == 192 ? 4 : 5) : (C == 48 ? 5 : 4);
+    static constexpr int MW1 = SH ? 4 : (NW == 8 ? (C == 192 ? 5 : 6) : (C == 48 ? 7 : 6));
+    static constexpr int MW2 = SH ? 3 : (NW == 8 ? (C == 192 ? 4 : 5) : (C == 48 ? 5 : 4));
     static constexpr int PWMAX = (C == 48) ? 76 : (C == 96 ? 40 : 24);      // widest padded row this width is instantiated for
     static constexpr int XMAX = 16 * MW1 * MPARTS + 2 * PWMAX;              // bound on X slots (patch pieces per thread)
-    static constexpr bool SUPPORTED = !(NW == 4 && C == 192);               // the 192-wide tile does not fit twice per CU
+    static constexpr bool SUPPORTED = !(NW == 4 && C == 192) && !(SH && (NW != 8 || C == 192));   // the 192-wide tile does not fit twice per CU
 };
 
 __device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }   // exact for x < 2^16
@@ -108,9 +110,9 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {           // bf16 
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
 }
 
-template <int C, int NW>
+template <int C, int NW, bool SH = false>
 __device__ __forceinline__ void bblock_item(const BBranch& a, int v, char* smem) {
-    typedef BCfg<C, NW> K;
+    typedef BCfg<C, NW, SH> K;
     constexpr int NSLAB = K::NSLAB, MPARTS = K::MPARTS, PA = K::PA, NCH = K::NCH, PWT = K::PWT, CHB = K::CHB, KS = K::KS;
     constexpr int MW1 = K::MW1, MW2 = K::MW2, PC8 = C / 8, D = K::D, T = 64 * NW;
     constexpr int NPX = (K::XMAX * PC8 + T - 1) / T;
@@ -375,14 +377,16 @@ __global__ __launch_bounds__(64 * NW) void k_bblock(BBArgs a) {
     for (int q = 1; q < PAM_BLOCK_MAX_BRANCHES; ++q) if (q < a.nbr && item >= a.br[q].item0) b = q;
     const BBranch& br = a.br[b];
     switch (br.C) {
-        case 48: bblock_item<48, NW>(br, item - br.item0, smem); break;
-        case 96: bblock_item<96, NW>(br, item - br.item0, smem); break;
+        case 48: if constexpr (NW == 8) { if (br.sh) { bblock_item<48, NW, true>(br, item - br.item0, smem); break; } }
+                 bblock_item<48, NW>(br, item - br.item0, smem); break;
+        case 96: if constexpr (NW == 8) { if (br.sh) { bblock_item<96, NW, true>(br, item - br.item0, smem); break; } }
+                 bblock_item<96, NW>(br, item - br.item0, smem); break;
         case 192: if constexpr (BCfg<192, NW>::SUPPORTED) bblock_item<192, NW>(br, item - br.item0, smem); break;
     }
 }
 
-template <int C, int NW> static size_t lds_for(int TH, int W) {
-    typedef BCfg<C, NW> K;
+template <int C, int NW, bool SH = false> static size_t lds_for(int TH, int W) {
+    typedef BCfg<C, NW, SH> K;
     const int PW = W + 2, XS = (TH + 4) * PW;
     size_t x = ((size_t)(XS + 2) * K::PA + 15) & ~(size_t)15;
     const size_t reach = (size_t)(16 * K::MW1 * K::MPARTS + 2 * PW + 2 + 1) * K::PA;    // junk M tiles read past the patch: keep it inside the allocation
@@ -390,8 +394,8 @@ template <int C, int NW> static size_t lds_for(int TH, int W) {
     if (reach > total) total = reach;
     return total;
 }
-template <int C, int NW> static int rows_for(int H, int W) {
-    typedef BCfg<C, NW> K;
+template <int C, int NW, bool SH = false> static int rows_for(int H, int W) {
+    typedef BCfg<C, NW, SH> K;
     if (!K::SUPPORTED || H < 1 || W < 1 || W + 2 > K::PWMAX) return 0;
     const int PW = W + 2;
     const size_t cap = NW == 4 ? 80 * 1024 : 160 * 1024;               // NW = 4 is only worth it with two workgroups per CU
@@ -400,12 +404,13 @@ template <int C, int NW> static int rows_for(int H, int W) {
     const int th2 = 16 * K::MW2 * K::MPARTS / PW;
     if (th2 < th) th = th2;
     if (th > H) th = H;
-    while (th >= 1 && lds_for<C, NW>(th, W) > cap) --th;
+    while (th >= 1 && lds_for<C, NW, SH>(th, W) > cap) --th;
     if (th < 1) return 0;
     for (int t = th; t >= 1 && t * 100 >= th * 75; --t) if (H % t == 0) return t;
     return th;
 }
-static int rows_dispatch(int C, int H, int W, int nw) {
+static int rows_dispatch(int C, int H, int W, int nw, int sh = 0) {
+    if (sh) return nw != 8 ? 0 : (C == 48 ? rows_for<48, 8, true>(H, W) : (C == 96 ? rows_for<96, 8, true>(H, W) : 0));
     switch (C * 10 + nw) {
         case 484: return rows_for<48, 4>(H, W);
         case 964: return rows_for<96, 4>(H, W);
@@ -415,7 +420,8 @@ static int rows_dispatch(int C, int H, int W, int nw) {
     }
     return 0;
 }
-static size_t lds_dispatch(int C, int th, int W, int nw) {
+static size_t lds_dispatch(int C, int th, int W, int nw, int sh = 0) {
+    if (sh) return nw != 8 ? ~(size_t)0 : (C == 48 ? lds_for<48, 8, true>(th, W) : (C == 96 ? lds_for<96, 8, true>(th, W) : ~(size_t)0));
     switch (C * 10 + nw) {
         case 484: return lds_for<48, 4>(th, W);
         case 964: return lds_for<96, 4>(th, W);
@@ -449,6 +455,9 @@ extern "C" int pam_basic_block_chunk_layout(int C, int32_t* out5) {
 
 extern "C" int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* d, int waves) {
     if (n_branches < 1 || n_branches > PAM_BLOCK_MAX_BRANCHES || !d) return PAM_E_ARG;
+    const int short_mask = (waves >> 4) & 0xf;          // bit k: branch k of the call runs as "short" 4-row items (8-wave form, C = 48 / 96)
+    waves &= 0xf;
+    if (short_mask && waves != 8) return PAM_E_ARG;
     if (waves != 4 && waves != 8) {                                    // auto: two workgroups per CU whenever every branch fits that way
         waves = 4;
         for (int k = 0; k < n_branches; ++k) if (rows_dispatch(d[k].C, d[k].H, d[k].W, 4) < 1) waves = 8;
@@ -458,17 +467,20 @@ extern "C" int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const 
     // widest first: the long items are dispatched first and the short ones fill in behind them
     int order[PAM_BLOCK_MAX_BRANCHES];
     for (int i = 0; i < n_branches; ++i) order[i] = i;
+    auto cost = [&](int k) { return d[k].C * (((short_mask >> k) & 1) ? 1 : 2); };      // per-item cost rank: width x tile height class
     for (int i = 0; i < n_branches; ++i)
         for (int j = i + 1; j < n_branches; ++j)
-            if (d[order[j]].C > d[order[i]].C) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+            if (cost(order[j]) > cost(order[i])) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
     int items = 0;
     size_t lds = 0;
     for (int k = 0; k < n_branches; ++k) {
         const PamBlockDesc& s = d[order[k]];
         if (!s.in || !s.w_img || !s.bias || !s.out || s.N < 1 || s.in == s.out) return PAM_E_ARG;
-        const int th = rows_dispatch(s.C, s.H, s.W, waves);
+        const int sh = (short_mask >> order[k]) & 1;
+        const int th = rows_dispatch(s.C, s.H, s.W, waves, sh);
         if (th < 1) return PAM_E_ARG;
         BBranch& b = a.br[k];
+        b.sh = sh;
         b.in = (const uint16_t*)s.in; b.wimg = (const uint16_t*)s.w_img; b.bias = s.bias; b.out = (uint16_t*)s.out;
         b.N = s.N; b.H = s.H; b.W = s.W; b.C = s.C; b.TH = th; b.tiles_y = (s.H + th - 1) / th;
         b.item0 = items; b.nitems = b.tiles_y * s.N; b.inv_pw = 1.0f / (float)(s.W + 2);
@@ -477,7 +489,7 @@ extern "C" int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const 
 #endif
         if ((size_t)s.N * s.H * s.W * s.C * 2 >= (1ull << 31)) return PAM_E_ARG;
         items += b.nitems;
-        const size_t l = lds_dispatch(s.C, th, s.W, waves);
+        const size_t l = lds_dispatch(s.C, th, s.W, waves, sh);
         if (l > lds) lds = l;
     }
     for (int k = n_branches; k < PAM_BLOCK_MAX_BRANCHES; ++k) a.br[k] = a.br[0];

@@ -591,11 +591,14 @@ class HipHRNet(ConvEngine):
     # depends on how a crop count's tile counts quantise on 256 CUs -- interleaved A/B, one device, vs 'grouped': 20 crops 'streamed96'
     # -2.8 %, 'unfused' -0.4 %; 28 crops 0 / +1.1 %; 40 crops +2.2 / +1.3 %; 60 crops -0.6 / -2.9 %; 112 crops +4.1 %; 217 crops +6.6 %.
     CONFIGS = {
-        'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0),      # branches 0 + 1 as one fused-BasicBlock launch per level
-        'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=0),     # one launch per convolution, 96-channel branch on k_conv3x3
-        'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=1),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
-        'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_streamed=1),   # branch 0 fused alone, branch 1 streamed
+        'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0, fuse_short=0),      # branches 0 + 1 as one fused-BasicBlock launch per level
+        'grouped_short96': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0, fuse_short=2),   # ... branch 1's items as 4-row tiles (twice the items, half the cost)
+        'grouped_short48': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0, fuse_short=1),   # ... branch 0's
+        'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=0, fuse_short=0),     # one launch per convolution, 96-channel branch on k_conv3x3
+        'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=1, fuse_short=0),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
+        'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_streamed=1, fuse_short=0),   # branch 0 fused alone, branch 1 streamed
     }
+    fuse_short = 0              # bit b: grouped branch b runs as "short" 4-row items (pam_basic_block_nhwc_bf16_ex, bits 4-7 of `waves`)
     c96_streamed = 0            # PAM_CONV_OPT_C96_STREAMED while THIS executor issues / captures a forward (a library-wide switch)
 
     def apply_config(self, name):
@@ -703,7 +706,7 @@ class HipHRNet(ConvEngine):
                 self._need(xs[b], 0)
             ys = [xs[b] for b in grouped]
             for k in range(len(mod['fused'][0])):
-                ys = self.basic_blocks([mod['fused'][b][k] for b in grouped], ys, self.fuse_waves)
+                ys = self.basic_blocks([mod['fused'][b][k] for b in grouped], ys, self.fuse_waves | ((self.fuse_short & ((1 << len(grouped)) - 1)) << 4))
             for b, y in zip(grouped, ys):
                 xs[b] = y
                 self._mark(y, 0)
@@ -791,7 +794,7 @@ class HipHRNet(ConvEngine):
                         cur.wait_stream(self._stream(b))
             ys = [xs[b] for b in grouped]
             for k in range(len(mod['fused'][0])):
-                ys = self.basic_blocks([mod['fused'][b][k] for b in grouped], ys, self.fuse_waves)
+                ys = self.basic_blocks([mod['fused'][b][k] for b in grouped], ys, self.fuse_waves | ((self.fuse_short & ((1 << len(grouped)) - 1)) << 4))
             for b, y in zip(grouped, ys):
                 xs[b] = y
             if self.multi_stream:

@@ -108,6 +108,29 @@ def test_grouped_launch_equals_single(eng):
     assert torch.equal(two4[0], single[0]) and torch.equal(two4[1], single[1])
 
 
+@pytest.mark.parametrize('shape', [(20, 96, 72), (3, 50, 72), (2, 7, 5)])
+def test_short_items_equal_normal_items(eng, shape):
+    """The "short" 4-row items (bits 4-7 of `waves`: a packing choice for grouped launches) compute exactly what the normal items do:
+    same K order per output element -> bit-equal, for either branch of a grouped 48 + 96 launch and for single launches."""
+    from pam import hrnet_hip
+    dev = eng.device
+    n, h, w = shape
+    ops, xs = [], []
+    for k, (c, hh, ww) in enumerate([(48, h, w), (96, max(1, h // 2), max(1, w // 2))]):
+        c1, c2 = make_block(c, 51 + k)
+        ops.append(hrnet_hip.PackedBlock(c1, c2, dev))
+        xs.append(torch.randn((n, c, hh, ww), generator=torch.Generator().manual_seed(3 + k)).to(torch.bfloat16).to(dev)
+                  .contiguous(memory_format=torch.channels_last))
+    ref = eng.basic_blocks(ops, xs, 8)
+    for mask in (1, 2, 3):
+        got = eng.basic_blocks(ops, xs, 8 | (mask << 4))
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), mask
+    one = eng.basic_blocks([ops[1]], [xs[1]], 8 | (1 << 4))[0]
+    torch.cuda.synchronize()
+    assert torch.equal(one, ref[1])
+
+
 def test_block_rejects_unsupported(eng):
     assert eng.lib.pam_basic_block_rows(384, 12, 9, 0) == 0
     assert eng.lib.pam_basic_block_rows(48, 96, 200, 0) == 0
