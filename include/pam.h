@@ -193,7 +193,9 @@ int pam_clock_probe(void* stream, unsigned long long* dev_out2, int microseconds
  * implicit GEMM on v_mfma_f32_16x16x32_bf16 with fused epilogue out = act(conv + bias [+ residual]); `relu` is the activation
  * code: 0 linear, 1 ReLU, 2 leaky ReLU (slope 0.1, Darknet); + 4 = add the residual AFTER the activation (Darknet shortcut).  w_packed is
  * [Cout][Kpad] bf16, k = (ky, kx, cin) flattened, zero-padded to Kpad = roundup(KH*KW*Cin, 64); bias float32 or NULL;
- * residual NHWC bf16 of the output shape or NULL.  tile_cfg: -1 = choose automatically, -2 = the classic kernels (k_conv3x3 /
+ * residual NHWC bf16 of the output shape or NULL.  tile_cfg: -1 = choose automatically (w_img in the layout pam_conv3x3_layout() announces
+ * at call time), -3 / -4 = the same with the layout of w_img STATED by the caller (-3 streamed: k_conv3x3s or PAM_E_ARG; -4 classic),
+ * -2 = the classic kernels (k_conv3x3 /
  * k_conv_igemm) with automatic tiles, 0..7 = one k_conv_igemm tile shape, 8 = the streamed implicit GEMM k_conv_gs (activation codes 0 / 1).  w_img (optional, 3x3 stride-1 layers
  * with Cin in {48,64,96,128,192,256,384,512}): the same weights pre-packed as per-chunk LDS images [Cout/BN][Cin/CK][BN][9*CK + pad] (BN =
  * pam_conv3x3_slab(H, W, Cin, Cout); CK = 48 if Cin == 48, 64 if Cin >= 192, else 32; row pitch 864 / 1184 / 608 bytes;

@@ -927,11 +927,11 @@ extern "C" int pam_conv_option(int key, int value) {
     g_conv_opt[key] = value;
     return old;
 }
-static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax, int& ntw) {
+static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax, int& ntw, bool allow96 = false) {
     // layer1 / transition1 of HRNet (64 -> 64 and 256 -> 48 at 96 x 72: ReLU layers; the detector's 64- and 256-channel 3x3 layers have
     // other widths and a leaky activation and stay on k_conv3x3): two rounds of 480 workgroups, still 24 -> 16 us and 59 -> 30 us
     const bool l1 = (Cin == 64 && Cout == 64) || (Cin == 256 && Cout == 48);
-    const bool c96 = Cin == 96 && Cout == 96 && g_conv_opt[PAM_CONV_OPT_C96_STREAMED] != 0;      // 48-channel slabs, two-slot ring
+    const bool c96 = Cin == 96 && Cout == 96 && (allow96 || g_conv_opt[PAM_CONV_OPT_C96_STREAMED] != 0);      // 48-channel slabs, two-slot ring
     if (Cin != 192 && Cin != 384 && !l1 && !c96) return false;
 #ifdef PAM_DIAG
     static const int mask = getenv("PAM_C3S_MASK") ? atoi(getenv("PAM_C3S_MASK")) : 14;      // tuning hook: 2 = Cin 192, 4 = 384, 8 = 64 / 256
@@ -1340,7 +1340,12 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
                                        int KH, int KW, int stride, int pad, int relu, int tile_cfg, int in_cstride, int relu_from) {
     if (in_cstride <= 0) in_cstride = Cin;
     if (in_cstride < Cin || in_cstride % 8 != 0 || relu_from < 0 || relu_from % 16 != 0) return PAM_E_ARG;
-    if (in_cstride != Cin || relu_from != 0) w_img = nullptr;          // sliced input / partial activation: generic kernel only
+    // tile_cfg -3 / -4: automatic like -1, but the caller STATES the layout of w_img (streamed / classic) instead of leaving it to
+    // pam_conv3x3_layout() at call time -- a launch recorded under one setting of pam_conv_option and re-issued under another must not
+    // read an image in the other layout
+    const bool force_streamed = tile_cfg == -3, no_streamed = tile_cfg == -4;
+    if (force_streamed || no_streamed) tile_cfg = -1;
+    if (in_cstride != Cin || relu_from != 0) { if (force_streamed) return PAM_E_ARG; w_img = nullptr; }   // sliced input / partial activation: generic kernel only
     const bool stem32 = w_img && Cin == 8 && Cout == 32 && KH == 3 && KW == 3 && pad == 1 && !residual && tile_cfg < 0 && stride <= 2;
     if (!in || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin % 8 != 0 || (Cout % 48 != 0 && Cout % 64 != 0 && !stem32) ||
         KH < 1 || KW < 1 || KH > 3 || KW > 3 || stride < 1)
@@ -1367,12 +1372,15 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         else pam_launch(k_conv_stem<1, 2>, grid, blk, 0, s, t);
         return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
     }
-    if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && tile_cfg == -1) {
+    if (force_streamed && !(w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1)) return PAM_E_ARG;
+    if (w_img && KH == 3 && KW == 3 && stride == 1 && pad == 1 && tile_cfg == -1 && !no_streamed) {
         // streamed kernel (specialised loader / multiplier waves): w_img then has the layout pam_conv3x3_layout() > 0 announces.
         // Any other tile_cfg (-2 = classic kernel, >= 100 = tuning hooks) takes the classic kernel and the classic images.
         C3Args c;
         int mt = 0, pmax = 0, ntw = 0;
-        if (c3s_pick(H, W, Cin, Cout, c.TH, mt, pmax, ntw)) {
+        const bool picked = c3s_pick(H, W, Cin, Cout, c.TH, mt, pmax, ntw, force_streamed);
+        if (force_streamed && !picked) return PAM_E_ARG;
+        if (picked) {
             if (relu > 1) return PAM_E_ARG;
             c.in = a.in; c.wimg = (const uint16_t*)w_img; c.bias = bias; c.res = a.res; c.out = a.out;
             c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.relu = relu; c.inv_pw = 1.0f / (float)(W + 2);

@@ -84,6 +84,7 @@ class PackedConv(object):
         bn = bn_s if streamed else lib.pam_conv3x3_slab(int(h), int(w), self.cin, self.cout)
         if self.cout % bn != 0:
             return None                                  # no whole number of slabs: the generic kernel takes this layer
+        self.last_streamed = streamed                    # layout of the image this call returns (conv() states it to the library)
         img = self._images.get((bn, streamed))
         if img is None:
             cin, cout = self.cin, self.cout
@@ -247,6 +248,10 @@ class ConvEngine(object):
         # (the detector's) ask for the classic kernels and the classic weight image
         tile_cfg = -2 if (self.tile_cfg == -1 and act > 1) else self.tile_cfg
         wimg = op.image(h, w, classic=(tile_cfg != -1)) if (in_cs == cin and relu_from == 0) else None
+        if tile_cfg == -1 and wimg is not None and op._stem is None:
+            # automatic choice, but the layout of THIS image is stated (-3 streamed / -4 classic): the launch may be re-issued later
+            # (bench.py's per-family timing) under another setting of the library's run-time options
+            tile_cfg = -3 if getattr(op, 'last_streamed', False) else -4
         st = torch.cuda.current_stream(x.device).cuda_stream
         launch = lambda: self.lib.pam_conv2d_nhwc_bf16_ex(
             C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),

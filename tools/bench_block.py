@@ -46,3 +46,7 @@ for k, wv in ((2, 4), (2, 8), (3, 8)):
     fl = sum(2 * 2.0 * args.n * h * w * c * c * 9 for c, h, w in SH[:k])
     tg = timeit(lambda: e.basic_blocks(ops[:k], xs[:k], wv))
     print('grouped %d branches, %d waves: %6.1f us (%5.0f TF/s)' % (k, wv, tg, fl / tg / 1e6), flush=True)
+for mask in (1, 2, 3):
+    fl = sum(2 * 2.0 * args.n * h * w * c * c * 9 for c, h, w in SH[:2])
+    tg = timeit(lambda: e.basic_blocks(ops[:2], xs[:2], 8 | (mask << 4)))
+    print('grouped 2 branches, 8 waves, short-item mask %d: %6.1f us (%5.0f TF/s)' % (mask, tg, fl / tg / 1e6), flush=True)
