@@ -597,13 +597,13 @@ class HipHRNet(ConvEngine):
     # -2.8 %, 'unfused' -0.4 %; 28 crops 0 / +1.1 %; 40 crops +2.2 / +1.3 %; 60 crops -0.6 / -2.9 %; 112 crops +4.1 %; 217 crops +6.6 %.
     CONFIGS = {
         'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0, fuse_short=0),      # branches 0 + 1 as one fused-BasicBlock launch per level
-        'grouped_short96': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0, fuse_short=2),   # ... branch 1's items as 4-row tiles (twice the items, half the cost)
-        'grouped_short48': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0, fuse_short=1),   # ... branch 0's
         'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=0, fuse_short=0),     # one launch per convolution, 96-channel branch on k_conv3x3
         'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=1, fuse_short=0),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
         'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_streamed=1, fuse_short=0),   # branch 0 fused alone, branch 1 streamed
     }
-    fuse_short = 0              # bit b: grouped branch b runs as "short" 4-row items (pam_basic_block_nhwc_bf16_ex, bits 4-7 of `waves`)
+    fuse_short = 0              # bit b: grouped branch b runs as "short" 4-row items (pam_basic_block_nhwc_bf16_ex, bits 4-7 of `waves`): meant to
+                                # pack the grouped launch better (360 items of 22-29 us on 256 CUs), measured SLOWER alone (47.7-47.9 vs 41.0 us
+                                # per grouped 48 + 96 block at 20 crops: more halo rows, fewer M tiles per weight fragment) -- not a tuner candidate
     c96_streamed = 0            # PAM_CONV_OPT_C96_STREAMED while THIS executor issues / captures a forward (a library-wide switch)
 
     def apply_config(self, name):
