@@ -141,6 +141,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('HIP extension missing: %s not built. Run `make -C %s` (needs hipcc, --offload-arch=gfx950). '
                            'There is no CPU fallback.' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    # One HIP runtime per process: libtorch_hip NEEDs "libamdhip64.so" (its bundled copy, SONAME libamdhip64.so.7) while
+    # this library NEEDs "libamdhip64.so.7".  With torch loaded first the loader satisfies ours from torch's copy by
+    # SONAME; the other way round it maps /opt/rocm's AND torch's, and the second runtime to initialise finds no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)

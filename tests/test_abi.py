@@ -95,3 +95,17 @@ def test_bench_counts_gpus_without_touching_hip(monkeypatch):
     monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False); monkeypatch.delenv('CUDA_VISIBLE_DEVICES', raising=False)
     assert b.visible_gpu_count() >= 0                   # no KFD here: falls back without raising
     assert b.algorithmic_bytes_per_frame(5, 4, 4, 5, 11) == 39520      # SURVEY 8d's Shelf figure
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """__graft_entry__.build() loads the library before anything imported torch; the process must still end up with a
+    single libamdhip64 mapped (two runtimes: the second to initialise reports 'no ROCm-capable device')."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import pam\nfrom pam import _lib\n_lib.load()\nimport torch\n"
+            "libs = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+            "print(len(libs), sorted(libs))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == '1', out.stdout
