@@ -5,11 +5,13 @@
     -> head + arg-max decode (HIP) -> [ONE all-gather of per-view keypoints when the views are sharded over ranks]
     -> fused tracker frame kernel (HIP): association + part-aware epipolar view filter + weighted DLT + smoothing + init.
 
-A step = one frame.  N = 1: the Shelf-like S2 workload (5 cameras 1032x776, 4 persons -> 20 crops per frame), the configuration
-BASELINE.json's metric is quoted on.  N > 1: the Panoptic-like S4 workload (31 cameras 1920x1080, 7 persons -> 217 crops per
-frame) with the CAMERA VIEWS partitioned over the ranks (each rank holds only its cameras' frames) and one all-gather of the
-per-view keypoint records per frame -- north_star's partition; the same line also carries the crop-balanced partition and rank 0
-running the whole S4 frame alone (the N = 1 point of the strong-scaling curve on the same workload).
+A step = one frame of the Shelf-like S2 workload (5 cameras 1032x776, 4 persons -> 20 crops per frame), the configuration
+BASELINE.json's metric is quoted on, at EVERY N: `value` at N = 1, 2, 4, 8 is one strong-scaling curve on one workload.  N > 1: the
+CAMERA VIEWS are partitioned over the ranks (each rank holds only its cameras' frames; 5 views keep at most 5 ranks busy) with one
+all-gather of the per-view keypoint records per frame -- north_star's partition.  The same line carries, for N > 1, the
+crop-balanced partition of the same frames, rank 0 running the whole frame alone, and `panoptic31`: the Panoptic-like S4 workload
+(31 cameras 1920x1080, 7 persons -> 217 crops per frame) view-sharded over the same ranks next to ITS single-GPU run -- the curve
+north_star asks for on Panoptic, on a frame heavy enough (24 ms on one GPU) for the partition to pay.
 
 All inputs (frames, person boxes, synthetic 2D keypoints) are resident in HBM before the timed region.  As SURVEY 8d prescribes,
 HRNet runs on real shapes with seeded random weights (no checkpoints offline); its decode output is computed, and the tracker
@@ -48,7 +50,7 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default=None, choices=['S1', 'S2', 'S3', 'S4'], help='default: S2 on one GPU, S4 on several')
+    ap.add_argument('--workload', default=None, choices=['S1', 'S2', 'S3', 'S4'], help='default: S2 (N > 1 adds the S4 runs as `panoptic31`)')
     ap.add_argument('--shard', default=None, choices=['views', 'crops'], help='default: crops on one GPU (= no exchange), views on several')
     ap.add_argument('--exchange', default='torch', choices=['torch', 'abi'], help="abi: the all-gather through pam_allgather_keypoints (RCCL called by the library; view sharding, real multi-GPU only)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -58,7 +60,7 @@ def parse_args():
     ap.add_argument('--no-h2d', action='store_true', help='skip the second timed run with the frames starting in pinned host memory')
     ap.add_argument('--no-drift', action='store_true')
     ap.add_argument('--no-pair', action='store_true', help='skip the throughput-mode run (two frames per conv-stack replay)')
-    ap.add_argument('--no-extra', action='store_true', help='N > 1: skip the crop-balanced run and the single-GPU run of the same workload')
+    ap.add_argument('--no-extra', action='store_true', help='N > 1: skip the crop-balanced run, the single-GPU run of the same workload and the Panoptic-31 runs')
     ap.add_argument('--batched-scenes', type=int, default=2048)
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-autotune', action='store_true', help="keep the conv stack in the executor's default configuration instead of the fastest per crop count")
@@ -356,6 +358,73 @@ def timed_run(torch, dist, pipe, step, inp, K, W, world, dev, events=True, feede
     return elapsed, evs, final
 
 
+def setup_workload(synth, size, nF):
+    """Sequence, matcher configuration and cameras of one synthetic workload (synth.SIZES)."""
+    from pam.ivclabpose import Camera, fundamental_matrices
+    meta = synth.SIZES[size]
+    seq = synth.make_sequence(size, n_frames=nF, seed=0)
+    cfg = dict(synth.MATCHER_CFG[synth.SIZE_TO_DATASET[size]]); conf = cfg.pop('CONF_THRESHOLD')
+    P32 = seq['calib']['P'].astype(np.float32); K32 = seq['calib']['K'].astype(np.float32)
+    RT32 = seq['calib']['RT'].astype(np.float32)
+    Fm = fundamental_matrices(K32, RT32)
+    cams = [Camera(j, P32[j], K32[j], RT32[j], Fm[j], w=meta['w'], h=meta['h']) for j in range(meta['C'])]
+    return dict(size=size, meta=meta, seq=seq, cfg=cfg, conf=conf, cams=cams, Fm=Fm)
+
+
+def scaling_extras(torch, dist, synth, args, wl, net, shard, K, W, world, rank, local_rank, dev, max_dets, fps_sharded):
+    """N > 1, after a sharded run of workload `wl`: the same frames with the OTHER partition (crops dealt evenly <-> camera views), and
+    rank 0 running the whole workload alone -- the N = 1 point of the strong-scaling curve on that workload.  Collective calls on
+    every rank; the returned dict is complete on rank 0."""
+    from pam.pipeline import FramePipeline
+    meta, size = wl['meta'], wl['size']
+    fh, fw = meta['h'], meta['w']
+    res = {}
+    other = 'crops' if shard == 'views' else 'views'
+    pipe2 = FramePipeline(wl['cams'], wl['cfg'], wl['conf'], (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world, rank=rank,
+                          use_graph=not args.no_graph, shard=other, overlap_tracker=not args.no_overlap, net=net)
+    inp2 = build_inputs(torch, synth, wl['seq'], size, max_dets, world, rank, other, dev, K + W)
+    el2, _, fin2 = timed_run(torch, dist, pipe2, make_step(pipe2, inp2, other), inp2, K, W, world, dev, events=False)
+    res['other_partition'] = {'sharding': other, 'value': K / el2, 'ms_per_step': el2 / K * 1e3, 'crops_per_rank': inp2['parts'],
+                              'final_tracks': [t['track_id'] for t in fin2['tracks'] if t['emitted']]}
+    del pipe2, inp2
+    if rank == 0:
+        K1, W1 = min(K, 20), min(W, 3)
+        pipe1 = FramePipeline(wl['cams'], wl['cfg'], wl['conf'], (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=1, rank=0,
+                              use_graph=not args.no_graph, shard='crops', overlap_tracker=not args.no_overlap, net=net)
+        inp1 = build_inputs(torch, synth, wl['seq'], size, max_dets, 1, 0, 'crops', dev, K1 + W1)
+        el1, _, fin1 = timed_run(torch, dist, pipe1, make_step(pipe1, inp1, 'crops'), inp1, K1, W1, 1, dev, events=False)
+        res['single_gpu_same_workload'] = {'value': K1 / el1, 'ms_per_step': el1 / K1 * 1e3, 'steps': K1,
+                                           'speedup_of_this_run': fps_sharded / (K1 / el1)}
+        del pipe1, inp1
+    dist.barrier()
+    return res
+
+
+def panoptic31_runs(torch, dist, synth, args, net, K, W, world, rank, local_rank, dev, max_dets, exchange):
+    """N > 1: the Panoptic-like S4 frame (31 HD cameras, 217 crops) with the camera views partitioned over the same ranks -- BASELINE
+    config 5 -- timed like the main run (barrier + synchronize pairs, MAX over ranks), plus scaling_extras() on that workload."""
+    from pam.pipeline import FramePipeline
+    from pam.distributed import view_partition
+    wl = setup_workload(synth, 'S4', K + W)
+    meta = wl['meta']
+    pipe = FramePipeline(wl['cams'], wl['cfg'], wl['conf'], (meta['h'], meta['w']), max_dets=max_dets, max_tracks=16, device=local_rank,
+                         world=world, rank=rank, use_graph=not args.no_graph, shard='views', overlap_tracker=not args.no_overlap,
+                         exchange=exchange, net=net)
+    inp = build_inputs(torch, synth, wl['seq'], 'S4', max_dets, world, rank, 'views', dev, K + W)
+    el, _, fin = timed_run(torch, dist, pipe, make_step(pipe, inp, 'views'), inp, K, W, world, dev, events=False)
+    res = {'workload': 'Panoptic-31-like S4: %d cams %dx%d, %d persons, %d crops/frame 384x288, 17 joints'
+                       % (meta['C'], meta['w'], meta['h'], meta['P'], int(np.median(inp['crops_per_frame']))),
+           'value': K / el, 'unit': 'frames/s', 'ms_per_step': el / K * 1e3, 'steps': K, 'warmup': W, 'scaling': 'strong',
+           'sharding': 'camera views partitioned over ranks, each rank holds its own cameras only',
+           'views_per_rank': [len(p) for p in view_partition(meta['C'], world)], 'crops_per_rank': inp['parts'],
+           'final_tracks': [t['track_id'] for t in fin['tracks'] if t['emitted']], 'tracker_status': fin['status'] | fin['status_sticky'],
+           'conv_executor': ({str(n): t['choice'] for n, t in net.tuned.items()} if net is not None and net.autotune else None)}
+    del pipe, inp
+    if not args.no_extra:
+        res.update(scaling_extras(torch, dist, synth, args, wl, net, 'views', K, W, world, rank, local_rank, dev, max_dets, res['value']))
+    return res
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -389,19 +458,13 @@ def main():
     from pam.pipeline import FramePipeline
     from pam.distributed import view_partition
 
-    size = args.workload or ('S2' if world == 1 else 'S4')
+    size = args.workload or 'S2'
     shard = args.shard or ('crops' if world == 1 else 'views')
-    meta = synth.SIZES[size]
-    C, P, fw, fh = meta['C'], meta['P'], meta['w'], meta['h']
     K, W = args.steps, args.warmup
     nF = K + W
-    seq = synth.make_sequence(size, n_frames=nF, seed=0)
-    dataset = synth.SIZE_TO_DATASET[size]
-    cfg = dict(synth.MATCHER_CFG[dataset]); conf = cfg.pop('CONF_THRESHOLD')
-    P32 = seq['calib']['P'].astype(np.float32); K32 = seq['calib']['K'].astype(np.float32)
-    RT32 = seq['calib']['RT'].astype(np.float32)
-    Fm = fundamental_matrices(K32, RT32)
-    cams = [Camera(j, P32[j], K32[j], RT32[j], Fm[j], w=fw, h=fh) for j in range(C)]
+    wl = setup_workload(synth, size, nF)
+    meta, seq, cfg, conf, cams, Fm = wl['meta'], wl['seq'], wl['cfg'], wl['conf'], wl['cams'], wl['Fm']
+    C, P, fw, fh = meta['C'], meta['P'], meta['w'], meta['h']
     max_dets = 8
     overlap = not args.no_overlap
     pipe = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world,
@@ -491,27 +554,17 @@ def main():
             'final_tracks': [t['track_id'] for t in final['tracks'] if t['emitted']], 'tracker_status': final['status'] | final['status_sticky'],
         }
 
-    # ---- N > 1: the same frames with the crop-balanced partition, and rank 0 running the whole workload alone ---------------------------
+    # ---- N > 1: the same frames with the other partition, rank 0 running the whole frame alone, and the Panoptic-31 workload -------------
     if world > 1 and not args.no_extra:
-        other = 'crops' if shard == 'views' else 'views'
-        pipe2 = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=world, rank=rank,
-                              use_graph=not args.no_graph, shard=other, overlap_tracker=not args.no_overlap, net=pipe.net)
-        inp2 = build_inputs(torch, synth, seq, size, max_dets, world, rank, other, dev, nF)
-        el2, _, fin2 = timed_run(torch, dist, pipe2, make_step(pipe2, inp2, other), inp2, K, W, world, dev, events=False)
+        ex = scaling_extras(torch, dist, synth, args, wl, pipe.net, shard, K, W, world, rank, local_rank, dev, max_dets, K / elapsed)
         if rank == 0:
-            out['other_partition'] = {'sharding': other, 'value': K / el2, 'ms_per_step': el2 / K * 1e3, 'crops_per_rank': inp2['parts'],
-                                      'final_tracks': [t['track_id'] for t in fin2['tracks'] if t['emitted']]}
-        del pipe2, inp2
-        if rank == 0:
-            K1, W1 = min(K, 20), min(W, 3)
-            pipe1 = FramePipeline(cams, cfg, conf, (fh, fw), max_dets=max_dets, max_tracks=16, device=local_rank, world=1, rank=0,
-                                  use_graph=not args.no_graph, shard='crops', overlap_tracker=not args.no_overlap, net=pipe.net)
-            inp1 = build_inputs(torch, synth, seq, size, max_dets, 1, 0, 'crops', dev, K1 + W1)
-            el1, _, fin1 = timed_run(torch, dist, pipe1, make_step(pipe1, inp1, 'crops'), inp1, K1, W1, 1, dev, events=False)
-            out['single_gpu_same_workload'] = {'value': K1 / el1, 'ms_per_step': el1 / K1 * 1e3, 'steps': K1,
-                                               'speedup_of_this_run': (K / elapsed) / (K1 / el1)}
-            del pipe1, inp1
-        dist.barrier()
+            out.update(ex)
+        if size != 'S4' and shard == 'views':
+            K4, W4 = min(K, 40), min(W, 4)
+            p31 = panoptic31_runs(torch, dist, synth, args, pipe.net, K4, W4, world, rank, local_rank, dev, max_dets,
+                                  args.exchange if not single_dev else 'torch')
+            if rank == 0:
+                out['panoptic31'] = p31
 
     # ---- secondary measurements on rank 0, after the timed region -------------------------------------------------------------------------
     if rank == 0:

@@ -60,6 +60,16 @@ def test_all_gather_world2_gloo():
         assert ret[0] and ret[1]
 
 
+def test_all_gather_with_a_rank_that_owns_no_view_gloo():
+    """Shelf's 5 views on 8 ranks leave 3 ranks without a camera (bench.py --gpus 8); here 2 views on 3 ranks: the idle rank sends a
+    padded empty record and still ends up with every view's keypoints."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    assert [len(p) for p in view_partition(2, 3)].count(0) == 1
+    mp.spawn(_worker, args=(3, _free_port(), 2, 4, ret), nprocs=3, join=True)
+    assert ret[0] and ret[1] and ret[2]
+
+
 def test_crop_partition_is_balanced_and_contiguous():
     for n in (0, 1, 7, 20, 217):
         for W in (1, 2, 4, 8):
