@@ -453,7 +453,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import pam  # noqa: F401
-    from pam import synth, hrnet as hrnet_mod
+    from pam import synth, hrnet as hrnet_mod, _lib as _pam_lib
     from pam.ivclabpose import Camera, fundamental_matrices
     from pam.pipeline import FramePipeline
     from pam.distributed import view_partition
@@ -537,7 +537,8 @@ def main():
                        'sharding': 'camera views partitioned over ranks, each rank holds its own cameras only' if shard == 'views'
                                    else 'crops dealt evenly over ranks',
                        'views_per_rank': [len(p) for p in view_partition(C, world)] if shard == 'views' else None,
-                       'tracker': 'fused HIP frame kernel (f64), replicated after the exchange', 'hrnet_weights': pipe.net.weights if pipe.net else None,
+                       'tracker': 'fused HIP frame kernel (f64), replicated after the exchange',
+                       'tracker_stream_on_its_own_hw_queue': bool(pipe.track_overlaps) if overlap else None, 'hrnet_weights': pipe.net.weights if pipe.net else None,
                        'conv_backend': pipe.net.backend if pipe.net else None,
                        'conv_executor': ({str(n): t for n, t in pipe.net.tuned.items()} if pipe.net is not None and pipe.net.autotune else
                                          (pipe.net.hip.config_name if pipe.net is not None and pipe.net.backend == 'hip' else None)),
@@ -577,7 +578,7 @@ def main():
             with torch.cuda.stream(side):
                 fn()
             torch.cuda.current_stream(dev).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
+            g = _pam_lib.immortal_graph(torch.cuda.CUDAGraph())      # never destroyed: see the helper
             with torch.cuda.graph(g):
                 for _ in range(iters):
                     fn()

@@ -154,6 +154,19 @@ def load():
     return lib
 
 
+
+def immortal_graph(graph):
+    """Every hipGraph this package captures lives until the process ends, and is not destroyed even then: destroying a captured
+    multi-stream graph on ROCm 7.2 corrupts the runtime's heap now and then (tools/graph_destroy_stress.py: 3 of 4 processes that
+    tune 40 crop counts -- 120 destroyed captures -- die of 'double free or corruption' / SIGSEGV in a LATER synchronize or
+    allocation, 0 of 2 when the captures are kept; the same abort showed up in 2 of ~35 bench runs while the tuner still dropped its
+    three slower captures per crop count).  One extra reference that is never returned keeps torch's CUDAGraph destructor
+    (hipGraphExecDestroy / hipGraphDestroy) from ever running; the tensors of a dropped capture still go back to the shared graph
+    pool, so what is retained is the executable graph itself."""
+    C.pythonapi.Py_IncRef(C.py_object(graph))
+    return graph
+
+
 class PamError(RuntimeError):
     pass
 

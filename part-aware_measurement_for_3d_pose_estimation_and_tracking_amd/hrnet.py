@@ -376,7 +376,7 @@ class HRNetPose(object):
                     for _ in range(2):
                         self._forward(static_in, kind)
                 torch.cuda.current_stream(self.device).wait_stream(s)
-                graph = torch.cuda.CUDAGraph()
+                graph = _lib.immortal_graph(torch.cuda.CUDAGraph())
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(graph, pool=self._pool):
@@ -397,7 +397,7 @@ class HRNetPose(object):
                 for _ in range(2):
                     self._forward(static_in, kind)
             torch.cuda.current_stream(self.device).wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
+            graph = _lib.immortal_graph(torch.cuda.CUDAGraph())
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             with torch.cuda.graph(graph, pool=self._pool):

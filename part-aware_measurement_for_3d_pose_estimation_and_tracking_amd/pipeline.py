@@ -60,11 +60,42 @@ class FramePipeline(object):
         self.out_i = torch.zeros((1, L.int_words), dtype=torch.int32).pin_memory()
         self.out_d = torch.zeros((1, L.dbl_words), dtype=torch.float64).pin_memory()
         self.ev = None
-        self.track_stream = torch.cuda.Stream(self.device) if overlap_tracker else None
+        self.track_stream, self.track_overlaps = self._pick_track_stream() if overlap_tracker else (None, False)
         self.ev_pose, self.ev_track, self._track_pending = torch.cuda.Event(), torch.cuda.Event(), False
         assert pose_streams in (1, 2) and (pose_streams == 1 or overlap_tracker), 'two pose streams need the tracker on its own stream'
         self.pose_streams = [torch.cuda.Stream(self.device) for _ in range(pose_streams)] if pose_streams > 1 else None
         self._frame_no = 0
+
+    def _pick_track_stream(self, tries=8, spin_us=400):
+        """A stream for the exchange + tracker that REALLY runs beside the caller's (pose) stream.  HIP streams are multiplexed onto a few
+        hardware queues (4 by default on ROCm 7.2) and a queue is in-order: the first stream the pool handed out sat on the pose stream's
+        queue, so frame t's 80 us tracker kernel ran in FRONT of frame t + 1's crop kernel instead of under its conv stack (rocprofv3
+        kernel trace, tools/frame_timeline.py: 110 us from the end of the head kernel to the next frame's first kernel, 10-20 us once
+        the two streams are on different queues; +4.6 % frames/s).  Which queue a stream gets is decided at its first use and cannot be
+        queried, so this measures it: two spin kernels (pam_clock_probe, one wave each), one per stream, take as long as ONE when the
+        queues differ and as long as two when they are the same.  Returns (stream, overlaps); the first candidate that overlaps wins."""
+        import ctypes as C
+        import time
+        pose = torch.cuda.current_stream(self.device)
+        out = torch.zeros(4, dtype=torch.int64, device=self.device)
+        lib = self.handle.lib
+
+        def both(s, us):
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for st, o in ((pose, out), (s, out[2:])):
+                if lib.pam_clock_probe(C.c_void_p(st.cuda_stream), C.c_void_p(o.data_ptr()), us) != 0:
+                    raise _lib.PamError('pam_clock_probe failed')
+            torch.cuda.synchronize(self.device)
+            return time.perf_counter() - t0
+        cands = []
+        for _ in range(tries):
+            s = torch.cuda.Stream(self.device)
+            cands.append(s)
+            both(s, 20)                                  # first use: the stream gets its hardware queue here
+            if min(both(s, spin_us) for _ in range(3)) < 1.5e-6 * spin_us:
+                return s, True
+        return cands[0], False
 
     def stream_ptr(self):
         return torch.cuda.current_stream(self.device).cuda_stream
