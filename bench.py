@@ -569,6 +569,8 @@ def main():
 
     # ---- secondary measurements on rank 0, after the timed region -------------------------------------------------------------------------
     if rank == 0:
+        ev_graphs = []
+
         def ev_time(fn, iters=50):
             """Seconds per call on the GPU: `iters` calls captured into one hipGraph and replayed between two HIP events, so that the
             host's launch cost (tens of us per call from Python) is not what gets measured."""
@@ -578,7 +580,7 @@ def main():
             with torch.cuda.stream(side):
                 fn()
             torch.cuda.current_stream(dev).wait_stream(side)
-            g = _pam_lib.immortal_graph(torch.cuda.CUDAGraph())      # never destroyed: see the helper
+            g = _pam_lib.new_graph(); ev_graphs.append(g)      # not destroyed in this process: see the helper
             with torch.cuda.graph(g):
                 for _ in range(iters):
                     fn()

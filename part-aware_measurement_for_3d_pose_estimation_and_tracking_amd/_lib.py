@@ -155,15 +155,35 @@ def load():
 
 
 
-def immortal_graph(graph):
-    """Every hipGraph this package captures lives until the process ends, and is not destroyed even then: destroying a captured
-    multi-stream graph on ROCm 7.2 corrupts the runtime's heap now and then (tools/graph_destroy_stress.py: 3 of 4 processes that
-    tune 40 crop counts -- 120 destroyed captures -- die of 'double free or corruption' / SIGSEGV in a LATER synchronize or
-    allocation, 0 of 2 when the captures are kept; the same abort showed up in 2 of ~35 bench runs while the tuner still dropped its
-    three slower captures per crop count).  One extra reference that is never returned keeps torch's CUDAGraph destructor
-    (hipGraphExecDestroy / hipGraphDestroy) from ever running; the tensors of a dropped capture still go back to the shared graph
-    pool, so what is retained is the executable graph itself."""
-    C.pythonapi.Py_IncRef(C.py_object(graph))
+_live_graphs = None
+
+
+def new_graph():
+    """A torch.cuda.CUDAGraph that is NOT destroyed while the interpreter shuts down (every graph the package captures is one).
+
+    Destroying a captured multi-stream graph on ROCm 7.2 corrupts the runtime's heap now and then (tools/graph_destroy_stress.py: 3 of
+    4 processes that tune 40 crop counts and destroy the 120 slower captures die of 'double free or corruption' / SIGSEGV inside a
+    LATER synchronize or allocation, 0 of 5 when nothing is destroyed; 2 of ~35 bench.py runs aborted the same way while the replay
+    tuner still dropped its slower captures at once).  So (i) the tuner keeps every capture for as long as its network lives
+    (HRNetPose._kept) -- a long-running process never destroys a graph -- and (ii) at interpreter exit every graph still alive gets
+    one reference that is never returned, so torch's destructor (hipGraphExecDestroy / hipGraphDestroy) does not run in the
+    teardown either and a finished run cannot turn into a non-zero exit code.  Graphs do die with their network when a process
+    drops one mid-run (the test-suite does); making them immortal outright was tried and is worse: with every capture of every
+    earlier network still alive, a replay in tests/test_gpu_image.py segfaults inside hipGraphLaunch (3 of 3 full-suite runs)."""
+    global _live_graphs
+    import torch
+    if _live_graphs is None:
+        import atexit
+        import weakref
+        _live_graphs = weakref.WeakSet()
+
+        def _keep():
+            for g in list(_live_graphs):
+                C.pythonapi.Py_IncRef(C.py_object(g))
+        atexit.register(_keep)
+
+    graph = torch.cuda.CUDAGraph()
+    _live_graphs.add(graph)
     return graph
 
 

@@ -298,7 +298,9 @@ class HRNetPose(object):
         # and a test that compares an eager forward with a replay needs both in ONE configuration.  FramePipeline / ivclabpose enable it.
         self.autotune = bool(autotune) and backend == 'hip' and use_graph
         self.tuned = {}                                   # crop count -> {'choice': name, 'ms': {name: ms per replay}}
-        self._pool = None
+        self._kept = []
+        self._pools = {}             # graph memory pool per replay slot: graphs of ONE slot replay one after the other and may share
+                                     # intermediates; the two slots of FramePipeline(pose_streams=2) replay concurrently and must not
         self.stream = torch.cuda.current_stream(self.device)
 
     # -- conv stack (PyTorch-ROCm; hipGraph replay per batch size) -------------------------------------------------
@@ -376,10 +378,8 @@ class HRNetPose(object):
                     for _ in range(2):
                         self._forward(static_in, kind)
                 torch.cuda.current_stream(self.device).wait_stream(s)
-                graph = _lib.immortal_graph(torch.cuda.CUDAGraph())
-                if self._pool is None:
-                    self._pool = torch.cuda.graph_pool_handle()
-                with torch.cuda.graph(graph, pool=self._pool):
+                graph = _lib.new_graph()
+                with torch.cuda.graph(graph, pool=self._pool_of(slot)):
                     static_out = self._forward(static_in, kind)
             g = (graph, static_in, static_out)
             self._graphs[(n, kind, slot)] = g
@@ -389,7 +389,7 @@ class HRNetPose(object):
         graph.replay()
         return static_out
 
-    def _capture(self, static_in, kind):
+    def _capture(self, static_in, kind, slot=0):
         with torch.no_grad():
             s = torch.cuda.Stream(self.device)
             s.wait_stream(torch.cuda.current_stream(self.device))
@@ -397,12 +397,15 @@ class HRNetPose(object):
                 for _ in range(2):
                     self._forward(static_in, kind)
             torch.cuda.current_stream(self.device).wait_stream(s)
-            graph = _lib.immortal_graph(torch.cuda.CUDAGraph())
-            if self._pool is None:
-                self._pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(graph, pool=self._pool):
+            graph = _lib.new_graph()
+            with torch.cuda.graph(graph, pool=self._pool_of(slot)):
                 static_out = self._forward(static_in, kind)
         return graph, static_in, static_out
+
+    def _pool_of(self, slot):
+        if slot not in self._pools:
+            self._pools[slot] = torch.cuda.graph_pool_handle()
+        return self._pools[slot]
 
     def _autotune(self, x, slot, reps=6):
         """Capture the n-crop forward in every executor configuration, time `reps` replays of each (after two warm ones), keep the
@@ -414,7 +417,7 @@ class HRNetPose(object):
         best, ms = None, {}
         for name in names:
             self.hip.apply_config(name)
-            g = self._capture(static_in, 'features')
+            g = self._capture(static_in, 'features', slot)
             if len(names) > 1:
                 for _ in range(2):
                     g[0].replay()
@@ -424,6 +427,7 @@ class HRNetPose(object):
                     g[0].replay()
                 b.record(); b.synchronize()
                 ms[name] = a.elapsed_time(b) / reps
+            self._kept.append(g[0])                       # the slower captures live as long as the network: _lib.track_graph
             if best is None or (len(names) > 1 and ms[name] < ms[best[0]]):
                 best = (name, g)
         if n not in self.tuned:

@@ -396,7 +396,7 @@ class YOLOv3(object):
                 with torch.cuda.stream(s):
                     self._run(ptrs, n, fh, fw, x8, boxes, count)
                 torch.cuda.current_stream(self.device).wait_stream(s)
-                graph = _lib.immortal_graph(torch.cuda.CUDAGraph())
+                graph = _lib.new_graph()
                 if self._pool is None:
                     self._pool = torch.cuda.graph_pool_handle()
                 with torch.cuda.graph(graph, pool=self._pool):
