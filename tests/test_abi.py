@@ -109,3 +109,27 @@ def test_one_hip_runtime_whatever_the_import_order():
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[0] == '1', out.stdout
+
+
+def test_bench_inputs_of_every_rank_for_the_shelf_frame_on_eight_ranks():
+    """bench.py --gpus 8 quotes `value` on the Shelf-like frame: 5 views over 8 ranks leave three ranks without a camera.  Their inputs
+    must still be well-formed (one padded empty record, no crops) and the ranks' crops must add up to the frame's, in both partitions."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    nF, world, max_dets = 3, 8, 8
+    wl = b.setup_workload(synth, 'S2', nF)
+    assert len(wl['cams']) == 5 and wl['meta']['C'] == 5
+    for shard in ('views', 'crops'):
+        per_rank = [b.build_inputs(torch, synth, wl['seq'], 'S2', max_dets, world, r, shard, torch.device('cpu'), nF) for r in range(world)]
+        for t in range(nF):
+            assert sum(i['local_crops'][t] for i in per_rank) == per_rank[0]['crops_per_frame'][t] == 20
+        assert per_rank[0]['parts'] == per_rank[world - 1]['parts'] and sum(per_rank[0]['parts']) == 20
+        if shard == 'views':
+            idle = [i for i in per_rank if not i['mine']]
+            assert len(idle) == 3
+            for i in idle:
+                e = i['per_frame'][0]
+                assert i['frames'] == [] and int(i['ptrs'].numel()) == 1 and e['vl'].numel() == 0 and e['nd'].numel() == 0
+                assert tuple(e['bx'].shape) == (0, 4) and tuple(e['dd'].shape) == (1, max_dets, 17, 3)
