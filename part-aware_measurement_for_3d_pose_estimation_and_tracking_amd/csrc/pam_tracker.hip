@@ -127,13 +127,13 @@ __host__ __device__ inline char* carve_ws(char* base, const Dims& d, Scratch& w)
 }
 __host__ __device__ inline size_t hot_bytes(const Dims& d) {
     Scratch w;
-    return ((size_t)(carve_ws_hot((char*)0, d, w) - (char*)0) + 15) & ~(size_t)15;
+    return ((size_t)(uintptr_t)carve_ws_hot((char*)0, d, w) + 15) & ~(size_t)15;      // offset from a zero base
 }
 // integer part of the scene state (everything before `vel`): contiguous, copied to LDS for the duration of a frame
 __host__ __device__ inline size_t state_int_bytes(const Dims& d) {
     SceneState s;
     carve_state((char*)0, d, s);
-    return (size_t)((char*)s.vel - (char*)0);
+    return (size_t)(uintptr_t)(char*)s.vel;
 }
 
 struct FrameArgs {
@@ -808,8 +808,8 @@ extern "C" int pam_create(PamHandle** out, int device, int n_views, int max_dets
     d.N2 = d.MAXH > max_dets ? d.MAXH : max_dets;
     h->prm = *params;
     SceneState st; Scratch ws;
-    h->state_stride = ((size_t)(carve_state((char*)0, d, st) - (char*)0) + 255) & ~(size_t)255;
-    h->ws_stride = ((size_t)(carve_ws((char*)0, d, ws) - (char*)0) + 255) & ~(size_t)255;
+    h->state_stride = ((size_t)(uintptr_t)carve_state((char*)0, d, st) + 255) & ~(size_t)255;
+    h->ws_stride = ((size_t)(uintptr_t)carve_ws((char*)0, d, ws) + 255) & ~(size_t)255;
     PamOutLayout& ol = h->ol;
     ol.n_views = d.C; ol.max_dets = d.MAXP; ol.max_tracks = d.MAXT; ol.n_scenes = d.S;
     ol.hdr_words = 4;
