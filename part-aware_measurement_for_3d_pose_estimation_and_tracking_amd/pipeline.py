@@ -73,7 +73,9 @@ class FramePipeline(object):
         kernel trace, tools/frame_timeline.py: 110 us from the end of the head kernel to the next frame's first kernel, 10-20 us once
         the two streams are on different queues; +4.6 % frames/s).  Which queue a stream gets is decided at its first use and cannot be
         queried, so this measures it: two spin kernels (pam_clock_probe, one wave each), one per stream, take as long as ONE when the
-        queues differ and as long as two when they are the same.  Returns (stream, overlaps); the first candidate that overlaps wins."""
+        queues differ and as long as two when they are the same.  Returns (stream, overlaps); the first candidate that overlaps wins.
+        The reference point is the stream that is current when the pipeline is built (frames are issued on the caller's current stream);
+        with pose_streams = 2 the frames run on two pool streams of their own, which this does not test against."""
         import ctypes as C
         import time
         pose = torch.cuda.current_stream(self.device)
