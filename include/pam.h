@@ -223,11 +223,11 @@ int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
  * 256 -> 48); the streamed kernel takes activation codes 0 / 1 only, so a layer with a Darknet code (relu > 1) must be packed in the
  * classic layout and called with tile_cfg == -2 (tile_cfg == -1 with a streamed image and relu > 1 returns PAM_E_ARG). */
 int pam_conv3x3_layout(int H, int W, int Cin, int Cout);
-/* run-time options of the convolution entry point, for experiments that must be switchable inside one process; returns the previous
- * value.  PAM_CONV_OPT_C96_STREAMED: 96 -> 96 3x3 stride-1 layers on the streamed kernel with 48-channel slabs (pam_conv3x3_layout()
- * then announces the streamed image for them; set it before the layer's weight image is packed). */
-#define PAM_CONV_OPT_C96_STREAMED 1
-int pam_conv_option(int key, int value);
+/* the same with the 96 -> 96 layers' choice stated: c96_slab 0 = they stay on k_conv3x3 (the answer above), 48 / 96 = streamed with
+ * slabs of that many output channels (96: the input patch is fetched once per tile instead of once per slab).  The caller packs the
+ * image for the slab returned and says so at the launch: tile_cfg -5 (slab 48) / -6 (slab 96) of pam_conv2d_nhwc_bf16_ex, which
+ * otherwise behave like -3 (streamed layout stated; -4 = classic layout stated). */
+int pam_conv3x3_layout_ex(int H, int W, int Cin, int Cout, int c96_slab);
 /* which kernel the calling thread's last pam_conv2d_nhwc_bf16[_ex] call launched (labels for per-kernel profiles) */
 #define PAM_CONV_KERNEL_IGEMM 0   /* k_conv_igemm */
 #define PAM_CONV_KERNEL_3X3   1   /* k_conv3x3   */
@@ -266,6 +266,18 @@ int pam_basic_block_nhwc_bf16(void* stream, int n_branches, const PamBlockDesc* 
  * with 8, bits 4-7 are a mask: bit k set = branch k of the call runs as "short" items (4-row tiles with their own M-tile counts: twice
  * the items at about half the cost each, C = 48 / 96) -- a packing choice for grouped launches, same results */
 int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* blocks, int waves);
+
+/* ---- the same BasicBlock with BOTH weight sets resident in LDS (csrc/pam_block2.hip; C = 48 only: 2 x 42 KB of weights beside a
+ * 75 KB input tile).  2-D tiles of tile_rows x tile_cols output positions, one 512-thread workgroup each; no barrier inside the K
+ * loops.  pam_basic_block2_tile writes the {rows, cols} the library would pick for N x H x W (whole rounds of 256 workgroups first,
+ * then the fewest M tiles per SIMD); tile_rows / tile_cols <= 0 in the launch = that choice.  Limits: (rows + 4)(cols + 4) <= 800,
+ * (rows + 2)(cols + 4) <= 768, rows (cols + 2) <= 640.
+ * wpack (86 016 + 1 024 bytes): [float32 bias: conv1's 48, conv2's 48, zero padding to 1 KiB][conv1's 14 k-step images][conv2's 14],
+ * a k-step image = [48 rows][64 bytes] exactly as pam_basic_block_nhwc_bf16's w_img for C = 48 (row permutation and piece swizzle
+ * above).  Results are bit-identical to pam_basic_block_nhwc_bf16's (same K order per output element).  in != out. */
+int pam_basic_block2_tile(int C, int N, int H, int W, int32_t* out2);
+int pam_basic_block2_nhwc_bf16(void* stream, const void* in, const void* wpack, void* out, int N, int H, int W, int C,
+                               int tile_rows, int tile_cols);
 
 /* ---- the pointwise tail of a layer1 Bottleneck as ONE launch (row a1; csrc/pam_pw.hip) ------------------------------------------
  * X = ReLU(W3 . y2 [+ Wd . x0] + bias3 [+ residual]);  y1 = ReLU(W1 . X + bias1)   per pixel, NHWC bf16:

@@ -91,7 +91,7 @@ _SIGS = {
     'pam_conv3x3_slab': (_I, [_I, _I, _I, _I]),
     'pam_conv3x3_layout': (_I, [_I, _I, _I, _I]),
     'pam_conv_last_kernel': (_I, []),
-    'pam_conv_option': (_I, [_I, _I]),
+    'pam_conv3x3_layout_ex': (_I, [_I, _I, _I, _I, _I]),
     'pam_conv_debug_stamps': (_I, [_P]),
     'pam_upsample_add_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
     'pam_upsample_add_nhwc_bf16_ex': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
@@ -99,6 +99,8 @@ _SIGS = {
     'pam_basic_block_chunk_layout': (_I, [_I, _P]),
     'pam_basic_block_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_basic_block_nhwc_bf16_ex': (_I, [_P, _I, _P, _I]),
+    'pam_basic_block2_tile': (_I, [_I, _I, _I, _I, _P]),
+    'pam_basic_block2_nhwc_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     'pam_pointwise64_relu_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, C.c_longlong]),
     'pam_bottleneck_tail_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I]),
     'pam_plan_begin': (_I, []),

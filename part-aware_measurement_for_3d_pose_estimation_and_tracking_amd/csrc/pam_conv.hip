@@ -919,19 +919,13 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
 // (LDS ring): the tile is the tallest whole-row tile that fits (a divisor of H when that costs < 15 %).
 // Cin 96 stays on k_conv3x3: its streamed form (96-channel slabs, 160 workgroups) is as fast alone (12.9 vs 13.0 us) but 3-5 % slower
 // end to end -- a 150 KB workgroup shuts the other branches out of its CU, and the 48 x 36 layers have enough tiles to fill the chip.
-// run-time options of the convolution entry point (pam_conv_option): experiments that must be switchable inside one process
-static int g_conv_opt[8] = {0};
-extern "C" int pam_conv_option(int key, int value) {
-    if (key < 0 || key >= 8) return PAM_E_ARG;
-    const int old = g_conv_opt[key];
-    g_conv_opt[key] = value;
-    return old;
-}
-static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax, int& ntw, bool allow96 = false) {
+// c96_slab: 0 = 96 -> 96 layers stay on k_conv3x3; 48 / 96 = they run here with slabs of that many output channels (the caller states it per
+// launch: tile_cfg -5 / -6 of pam_conv2d_nhwc_bf16_ex, and packs the weight image for that slab: pam_conv3x3_layout_ex)
+static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax, int& ntw, int c96_slab = 0) {
     // layer1 / transition1 of HRNet (64 -> 64 and 256 -> 48 at 96 x 72: ReLU layers; the detector's 64- and 256-channel 3x3 layers have
     // other widths and a leaky activation and stay on k_conv3x3): two rounds of 480 workgroups, still 24 -> 16 us and 59 -> 30 us
     const bool l1 = (Cin == 64 && Cout == 64) || (Cin == 256 && Cout == 48);
-    const bool c96 = Cin == 96 && Cout == 96 && (allow96 || g_conv_opt[PAM_CONV_OPT_C96_STREAMED] != 0);      // 48-channel slabs, two-slot ring
+    const bool c96 = Cin == 96 && Cout == 96 && (c96_slab == 48 || c96_slab == 96);
     if (Cin != 192 && Cin != 384 && !l1 && !c96) return false;
 #ifdef PAM_DIAG
     static const int mask = getenv("PAM_C3S_MASK") ? atoi(getenv("PAM_C3S_MASK")) : 14;      // tuning hook: 2 = Cin 192, 4 = 384, 8 = 64 / 256
@@ -956,11 +950,12 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
         // the instantiated (M tiles per wave, patch slots) shapes: (3, 192), (4, 320), (5, 384 | 448) -- the smallest that holds the tile
         const int m = (sl <= 192 && np <= 192) ? 3 : ((sl <= 256 && np <= 320) ? 4 : ((sl <= 320 && np <= 448) ? 5 : 8));
         if (m == 8 && !tall) continue;
+        if (m == 5 && c96 && c96_slab == 96) continue;         // 5 x 6 accumulator tiles per wave do not fit 256 registers
         const long cost = (long)((H + t - 1) / t) * m;
         if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : (m == 8 ? 576 : (np <= 384 ? 384 : 448))); }
     }
     if (TH < 1) return false;
-    const int bn = (Cout == 48 || c96) ? 48 : 64;
+    const int bn = c96 ? c96_slab : (Cout == 48 ? 48 : 64);
     if (Cout % bn != 0) return false;
     ntw = bn / 16;
     if (c96) return true;
@@ -969,10 +964,11 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
     if (Cin == 256 ? ntw != 3 : ntw != 4) return false;
     return true;
 }
-extern "C" int pam_conv3x3_layout(int H, int W, int Cin, int Cout) {
+extern "C" int pam_conv3x3_layout_ex(int H, int W, int Cin, int Cout, int c96_slab) {
     int th, mt, pmax, ntw;
-    return c3s_pick(H, W, Cin, Cout, th, mt, pmax, ntw) ? 16 * ntw : 0;
+    return c3s_pick(H, W, Cin, Cout, th, mt, pmax, ntw, c96_slab) ? 16 * ntw : 0;
 }
+extern "C" int pam_conv3x3_layout(int H, int W, int Cin, int Cout) { return pam_conv3x3_layout_ex(H, W, Cin, Cout, 0); }
 template <int CIN, int NTW, int MT, int PMAX, int NBUF>
 static int launch_c3s_one(hipStream_t s, const C3Args& a) {
     constexpr size_t lds = (size_t)NBUF * (PMAX * 64 + 9 * 16 * NTW * 64);
@@ -1008,6 +1004,8 @@ static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, 
         case 9633: return launch_c3s_one<96, 3, 3, 192, 2>(s, a);
         case 9634: return launch_c3s_one<96, 3, 4, 320, 2>(s, a);
         case 9635: return launch_c3s_one<96, 3, 5, 384, 2>(s, a);
+        case 9663: return launch_c3s_one<96, 6, 3, 192, 2>(s, a);      // all 96 output channels per workgroup: the patch is fetched once
+        case 9664: return launch_c3s_one<96, 6, 4, 320, 2>(s, a);
         case 19248: return launch_c3s_one<192, 4, 8, 576, 2>(s, a);
         case 19243: return launch_c3s_one<192, 4, 3, 192, 3>(s, a);
         case 19244: return launch_c3s_one<192, 4, 4, 320, 2>(s, a);
@@ -1343,7 +1341,9 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     // tile_cfg -3 / -4: automatic like -1, but the caller STATES the layout of w_img (streamed / classic) instead of leaving it to
     // pam_conv3x3_layout() at call time -- a launch recorded under one setting of pam_conv_option and re-issued under another must not
     // read an image in the other layout
-    const bool force_streamed = tile_cfg == -3, no_streamed = tile_cfg == -4;
+    // -5 / -6: streamed, and a 96 -> 96 layer's image is packed for slabs of 48 / 96 output channels
+    const int c96_slab = tile_cfg == -5 ? 48 : (tile_cfg == -6 ? 96 : 0);
+    const bool force_streamed = tile_cfg == -3 || c96_slab != 0, no_streamed = tile_cfg == -4;
     if (force_streamed || no_streamed) tile_cfg = -1;
     if (in_cstride != Cin || relu_from != 0) { if (force_streamed) return PAM_E_ARG; w_img = nullptr; }   // sliced input / partial activation: generic kernel only
     const bool stem32 = w_img && Cin == 8 && Cout == 32 && KH == 3 && KW == 3 && pad == 1 && !residual && tile_cfg < 0 && stride <= 2;
@@ -1378,7 +1378,7 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
         // Any other tile_cfg (-2 = classic kernel, >= 100 = tuning hooks) takes the classic kernel and the classic images.
         C3Args c;
         int mt = 0, pmax = 0, ntw = 0;
-        const bool picked = c3s_pick(H, W, Cin, Cout, c.TH, mt, pmax, ntw, force_streamed);
+        const bool picked = c3s_pick(H, W, Cin, Cout, c.TH, mt, pmax, ntw, c96_slab);
         if (force_streamed && !picked) return PAM_E_ARG;
         if (picked) {
             if (relu > 1) return PAM_E_ARG;

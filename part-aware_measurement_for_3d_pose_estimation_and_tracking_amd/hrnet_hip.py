@@ -70,7 +70,7 @@ class PackedConv(object):
             m.bias.copy_(torch.cat([(c.bias.detach().float() if c.bias is not None else torch.zeros(c.out_channels)) for c in convs]))
         return PackedConv(m, device)
 
-    def image(self, h, w, classic=False):
+    def image(self, h, w, classic=False, c96_slab=0):
         """Weight image of this layer at input h x w for the rows-in-LDS kernels (layouts: include/pam.h): the classic per-chunk image
         [cout/BN][cin/CK][BN][pitch/2] (row = 9 taps x CK channels + pad), or -- where pam_conv3x3_layout() says so and the caller does
         not force the classic kernel -- the streamed kernel's [cout/BN][cin/32][9][BN][4][8] with swizzled 16-byte pieces."""
@@ -79,12 +79,13 @@ class PackedConv(object):
         if self._w_ohwi is None:
             return None
         lib = _lib.load()
-        bn_s = 0 if classic else lib.pam_conv3x3_layout(int(h), int(w), self.cin, self.cout)     # > 0: streamed kernel, with this slab width
+        bn_s = 0 if classic else lib.pam_conv3x3_layout_ex(int(h), int(w), self.cin, self.cout, int(c96_slab))     # > 0: streamed kernel, with this slab width
         streamed = bn_s > 0
         bn = bn_s if streamed else lib.pam_conv3x3_slab(int(h), int(w), self.cin, self.cout)
         if self.cout % bn != 0:
             return None                                  # no whole number of slabs: the generic kernel takes this layer
         self.last_streamed = streamed                    # layout of the image this call returns (conv() states it to the library)
+        self.last_c96 = bn if (streamed and self.cin == 96 and self.cout == 96) else 0
         img = self._images.get((bn, streamed))
         if img is None:
             cin, cout = self.cin, self.cout
@@ -122,23 +123,39 @@ class PackedBlock(object):
             raise _lib.PamError('no fused-block kernel for %d channels' % c)
         ks, nch, pwt, chb, nstep = [int(v) for v in lay]
         assert pwt == 64 and chb == ks * c * 64 and nstep == ks * nch and nstep * 32 >= 9 * c, (ks, nch, pwt, chb, nstep)
+        def images(chan):
+            """[2][nch][ks][C rows][4 pieces][8]: row R of a k-step image = output channel chan[R], 16-byte pieces bank-swizzled."""
+            rows = torch.arange(c)
+            sigma = torch.tensor([0, 2, 3, 1])[(rows % 16) >> 2]                      # bank swizzle of the 16-byte pieces of a row
+            src = torch.arange(4)[None, :] ^ sigma[:, None]                            # physical piece p of row r holds logical piece p ^ sigma[r]
+            img = torch.zeros((2, nch, ks, c, 4, 8), dtype=torch.float32)
+            for cv, conv in enumerate((conv1, conv2)):
+                w = conv.weight.detach().float().permute(0, 2, 3, 1).reshape(c, 9 * c)[chan]       # [row][k = tap * C + cin]
+                wk = torch.zeros((c, nstep * 32), dtype=torch.float32)
+                wk[:, :9 * c] = w
+                wk = wk.reshape(c, nstep, 4, 8)                                        # [row][k-step][piece][8]
+                wk = torch.gather(wk, 2, src[:, None, :, None].expand(c, nstep, 4, 8))
+                img[cv] = wk.permute(1, 0, 2, 3).reshape(nch, ks, c, 4, 8)             # chunk = ks consecutive k-step sub-images [row][4][8]
+            return img
         rows = torch.arange(c)
-        chan = 48 * (rows // 48) + 12 * ((rows % 16) >> 2) + 4 * ((rows % 48) // 16) + (rows & 3)
-        sigma = torch.tensor([0, 2, 3, 1])[(rows % 16) >> 2]                      # bank swizzle of the 16-byte pieces of a row
-        src = torch.arange(4)[None, :] ^ sigma[:, None]                            # physical piece p of row r holds logical piece p ^ sigma[r]
-        img = torch.zeros((2, nch, ks, c, 4, 8), dtype=torch.float32)
-        for cv, conv in enumerate((conv1, conv2)):
-            w = conv.weight.detach().float().permute(0, 2, 3, 1).reshape(c, 9 * c)[chan]       # [row][k = tap * C + cin]
-            wk = torch.zeros((c, nstep * 32), dtype=torch.float32)
-            wk[:, :9 * c] = w
-            wk = wk.reshape(c, nstep, 4, 8)                                        # [row][k-step][piece][8]
-            wk = torch.gather(wk, 2, src[:, None, :, None].expand(c, nstep, 4, 8))
-            img[cv] = wk.permute(1, 0, 2, 3).reshape(nch, ks, c, 4, 8)             # chunk = ks consecutive k-step sub-images [row][4][8]
+        img = images(48 * (rows // 48) + 12 * ((rows % 16) >> 2) + 4 * ((rows % 48) // 16) + (rows & 3))
         self.w_img = img.to(torch.bfloat16).to(device).contiguous()
         zb = lambda cv: cv.bias.detach().float() if cv.bias is not None else torch.zeros(c)
         self.bias = torch.stack([zb(conv1), zb(conv2)]).to(device).contiguous()
         self.c = c
         self.c1 = self.c2 = None            # the unfused PackedConv pair (fallback for shapes the fused kernel does not take)
+        # the resident-weights kernel (csrc/pam_block2.hip, C = 48) takes ONE buffer: [float32 bias padded to 1 KiB][conv1's k-step
+        # images][conv2's] -- the k-step images are the ones above
+        self.wpack = None
+        if c == 48:
+            # its rows: N tiles 0, 1 = channels 8 q' + 4 j + r, N tile 2 = 32 + 4 q' + r (q' = (R % 16) >> 2, r = R & 3): a lane ends with
+            # channels 8 g .. 8 g + 7 and 32 + 4 g .. + 3 -- aligned 16 + 8 bytes of a pixel
+            j, qq, r = rows // 16, (rows % 16) >> 2, rows & 3
+            chan2 = torch.where(j < 2, 8 * qq + 4 * j + r, 32 + 4 * qq + r)
+            head = torch.zeros(256, dtype=torch.float32)
+            head[:2 * c] = self.bias.reshape(-1).cpu()
+            self.wpack = torch.cat([head.view(torch.uint8), images(chan2).to(torch.bfloat16).reshape(-1).view(torch.uint8)]).to(device).contiguous()
+            assert self.wpack.numel() == 1024 + 2 * 14 * 48 * 64
 
 
 class PackedTail(object):
@@ -223,6 +240,7 @@ class ConvEngine(object):
         if self.prof is not None and x.device.type == 'cuda':
             self.prof.append(dict(family=family, sig=(family,) + tuple(sig), bytes=nbytes, flops=flops, fn=fn))
     tile_cfg = -1
+    c96_slab = 0                # 96 -> 96 3x3 layers: 0 = k_conv3x3, 48 / 96 = the streamed kernel with slabs of that many output channels
     _keep = None
     ACT = {None: 0, False: 0, True: 1, 'linear': 0, 'relu': 1, 'leaky': 2}
 
@@ -247,11 +265,11 @@ class ConvEngine(object):
         # the streamed kernels (k_conv3x3s / k_conv_gs) take the activation codes 0 / 1 only: leaky / shortcut-after-activation layers
         # (the detector's) ask for the classic kernels and the classic weight image
         tile_cfg = -2 if (self.tile_cfg == -1 and act > 1) else self.tile_cfg
-        wimg = op.image(h, w, classic=(tile_cfg != -1)) if (in_cs == cin and relu_from == 0) else None
+        wimg = op.image(h, w, classic=(tile_cfg != -1), c96_slab=self.c96_slab) if (in_cs == cin and relu_from == 0) else None
         if tile_cfg == -1 and wimg is not None and op._stem is None:
-            # automatic choice, but the layout of THIS image is stated (-3 streamed / -4 classic): the launch may be re-issued later
-            # (bench.py's per-family timing) under another setting of the library's run-time options
-            tile_cfg = -3 if getattr(op, 'last_streamed', False) else -4
+            # automatic choice, but the layout of THIS image is stated: -3 streamed / -4 classic, -5 / -6 a 96 -> 96 layer streamed with
+            # slabs of 48 / 96 output channels (the executor's choice, c96_slab)
+            tile_cfg = ({48: -5, 96: -6}.get(getattr(op, 'last_c96', 0), -3)) if getattr(op, 'last_streamed', False) else -4
         st = torch.cuda.current_stream(x.device).cuda_stream
         launch = lambda: self.lib.pam_conv2d_nhwc_bf16_ex(
             C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()), C.c_void_p(op.w.data_ptr()),
@@ -305,6 +323,36 @@ class ConvEngine(object):
                        sum(2 * (2 * x.numel() + 2 * 9 * o.c * o.c) + 8 * o.c for o, x in zip(ops, xs)),
                        sum(2 * 2 * x.numel() * 9 * o.c for o, x in zip(ops, xs)), launch)
         return ys
+
+    def basic_block2(self, op, x, tile=None):
+        """One BasicBlock (PackedBlock with ``wpack``: C = 48) on x through the resident-weights kernel; tile = (rows, cols) or None."""
+        n, c, h, w = x.shape
+        assert c == op.c and op.wpack is not None, (x.shape, op.c)
+        y = torch.empty_like(x)
+        if self._keep is not None:
+            self._keep.append(y)
+        nbytes, flops = 2 * (2 * x.numel() + 2 * 9 * c * c) + 8 * c, 2 * 2 * x.numel() * 9 * c
+        if self.count is not None:
+            self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
+        if x.device.type == 'meta':
+            return y
+        assert x.is_contiguous(memory_format=torch.channels_last)
+        if tile is None:
+            tile = self._bb2_tiles.get((n, h, w))
+            if tile is None:
+                t2 = (C.c_int32 * 2)()
+                if self.lib.pam_basic_block2_tile(c, n, h, w, t2) != 0:
+                    raise _lib.PamError('no resident-weights block tile for %s' % (tuple(x.shape),))
+                tile = self._bb2_tiles[(n, h, w)] = (int(t2[0]), int(t2[1]))
+        launch = lambda: self.lib.pam_basic_block2_nhwc_bf16(C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()),
+                                                              C.c_void_p(op.wpack.data_ptr()), C.c_void_p(y.data_ptr()), n, h, w, c, tile[0], tile[1])
+        rc = launch()
+        if rc != 0:
+            raise _lib.PamError('pam_basic_block2_nhwc_bf16 failed (%d) for %s tile %s' % (rc, tuple(x.shape), tile))
+        self._prof_add(x, 'k_bblock2 C=%d' % c, (n, h, w, c) + tuple(tile), nbytes, flops, launch)
+        return y
+
+    _bb2_tiles = {}             # (N, H, W) -> the library's tile choice (pam_basic_block2_tile searches ~H x W candidates)
 
     def pointwise64(self, op, x):
         """ReLU(conv1x1 64 -> 64 (x)) as a pure stream (k_pw1)."""
@@ -596,15 +644,17 @@ class HipHRNet(ConvEngine):
     # depends on how a crop count's tile counts quantise on 256 CUs -- interleaved A/B, one device, vs 'grouped': 20 crops 'streamed96'
     # -2.8 %, 'unfused' -0.4 %; 28 crops 0 / +1.1 %; 40 crops +2.2 / +1.3 %; 60 crops -0.6 / -2.9 %; 112 crops +4.1 %; 217 crops +6.6 %.
     CONFIGS = {
-        'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_streamed=0, fuse_short=0),      # branches 0 + 1 as one fused-BasicBlock launch per level
-        'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=0, fuse_short=0),     # one launch per convolution, 96-channel branch on k_conv3x3
-        'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_streamed=1, fuse_short=0),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
-        'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_streamed=1, fuse_short=0),   # branch 0 fused alone, branch 1 streamed
+        'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=False),      # branches 0 + 1 as one fused-BasicBlock launch per level
+        'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=False),     # one launch per convolution, 96-channel branch on k_conv3x3
+        'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=False),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
+        'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_slab=48, fuse_short=0, block2=False),   # branch 0 fused alone (ring kernel), branch 1 streamed
+        'resident48_streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=True),   # branch 0 on the resident-weights fused block
+        'resident48': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=True),
+        'resident48_wide96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=96, fuse_short=0, block2=True),         # ... 96-channel slabs: the patch is fetched once
     }
     fuse_short = 0              # bit b: grouped branch b runs as "short" 4-row items (pam_basic_block_nhwc_bf16_ex, bits 4-7 of `waves`): meant to
                                 # pack the grouped launch better (360 items of 22-29 us on 256 CUs), measured SLOWER alone (47.7-47.9 vs 41.0 us
                                 # per grouped 48 + 96 block at 20 crops: more halo rows, fewer M tiles per weight fragment) -- not a tuner candidate
-    c96_streamed = 0            # PAM_CONV_OPT_C96_STREAMED while THIS executor issues / captures a forward (a library-wide switch)
 
     def apply_config(self, name):
         for k, v in self.CONFIGS[name].items():
@@ -721,9 +771,7 @@ class HipHRNet(ConvEngine):
             with self._on(b):
                 x = xs[b]
                 self._need(x, b)
-                for c1, c2 in blocks:
-                    y = self.conv(c1, x, relu=True)
-                    x = self.conv(c2, y, res=x, relu=True)
+                x = self._branch_blocks(mod, b, blocks, x)
                 xs[b] = x
                 # the 1x1 up-convolutions first: they feed the FINER outputs, whose next chains are the longest
                 mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up) else None
@@ -767,6 +815,49 @@ class HipHRNet(ConvEngine):
                 out[i] = self.upsample_add(xs[i], [t for t, _, _ in tl], [sh for _, sh, _ in tl], relu=True) if tl else torch.relu(xs[i])
                 self._mark(out[i], i)
         return out
+
+    stamp = None                # diagnostics (tools/fwd_stamps.py): callable(tag) issued on the current stream at points of the schedule
+
+    def _st(self, tag):
+        if self.stamp is not None:
+            self.stamp(tag)
+
+    knock_out = 0               # diagnostics: bit b = skip the BasicBlocks of branch b (what would a free branch be worth)
+    block2 = False              # 48-channel branch: one resident-weights fused BasicBlock launch per block (csrc/pam_block2.hip)
+
+    def _branch_blocks(self, mod, b, blocks, x):
+        """The BasicBlocks of branch b that no grouped launch took, on the current stream."""
+        fused = mod['fused'][b]
+        if self.knock_out & (1 << b):                   # diagnostics (tools/ab_flags.py): the branch's blocks are not issued at all
+            return x
+        # staggered start: this branch's chain begins behind block k of branch 0 (a fork-style edge from the caller's stream, the one
+        # cross-stream dependency hipGraph capture takes on ROCm 7.2) -- see `stagger`
+        nb = len(mod['branches'])
+        k = self.stagger.get(nb, ())[b] if (self.multi_stream and not self.plan_rec and b < len(self.stagger.get(nb, ()))) else 0
+        if b > 0 and k > 0 and x.device.type == 'cuda' and len(self._b0_events) >= k:
+            torch.cuda.current_stream(self.device).wait_event(self._b0_events[k - 1])
+        if b == 0:
+            self._b0_events = []
+
+        def done():
+            if b == 0 and self.multi_stream and not self.plan_rec and x.device.type == 'cuda' and any(self.stagger.get(nb, ())):
+                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device)); self._b0_events.append(ev)
+        if self.block2 and blocks and fused is not None and fused[0].wpack is not None:
+            for op in fused:
+                x = self.basic_block2(op, x); done()
+            return x
+        for c1, c2 in blocks:
+            y = self.conv(c1, x, relu=True)
+            x = self.conv(c2, y, res=x, relu=True); done()
+        return x
+
+    # Which branch finishes last decides how much of a module's fuse layer is exposed: the strided-conv chains hang off the FINE
+    # branches (from branch 0: up to three dependent convolutions), the coarsest branch only feeds 1x1 up-convolutions.  Sharing the
+    # chip fairly, the four chains end together and the longest tail runs on an idle chip (un-profiled timeline: tools/fwd_stamps.py).
+    # stagger[nb][b] = k: in a module of nb branches, branch b starts behind block k of branch 0 (0 = at once), so the coarse branches
+    # end last and the fine branches' tails run beside them.
+    stagger = {}
+    _b0_events = ()
 
     def _hr_module(self, mod, xs):
         """xs[b]: tensor, or ('lazy', transition op, source tensor) for a branch this stage creates."""
@@ -812,9 +903,9 @@ class HipHRNet(ConvEngine):
                 x = xs[b]
                 if isinstance(x, tuple):                              # transition conv runs on the new branch's own stream
                     x = self.conv(x[1], x[2], relu=True)
-                for c1, c2 in blocks:
-                    y = self.conv(c1, x, relu=True)
-                    x = self.conv(c2, y, res=x, relu=True)
+                self._st('b%d start' % b)
+                x = self._branch_blocks(mod, b, blocks, x)
+                self._st('b%d blocks' % b)
                 xs[b] = x
                 if self.group_fuse:
                     continue
@@ -840,15 +931,18 @@ class HipHRNet(ConvEngine):
                         for k, op in enumerate(ops):
                             t = self.conv(op, t, relu=(k0 + k < len(f[1]) - 1))
                         terms[i][b] = (t, 0)
+                self._st('b%d tail' % b)
         if self.group_fuse:
             return self._fuse_grouped(mod, xs)
         self._barrier()
+        self._st('join')
         # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order
         out = [None] * len(fuse)
         for i in [q for q in self.order if q < len(fuse)]:
             with torch.cuda.stream(self._stream(i)):
                 tl = [terms[i][j] for j in sorted(terms[i])]
                 out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])
+                self._st('sum%d' % i)
         return out
 
     def _fuse_grouped(self, mod, xs):
@@ -923,13 +1017,7 @@ class HipHRNet(ConvEngine):
         """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
         self._keep = []
         self._evt = {}
-        if not self.c96_streamed:
-            return self._features(x8)
-        old = self.lib.pam_conv_option(1, 1)              # PAM_CONV_OPT_C96_STREAMED: decided at launch (and capture) time
-        try:
-            return self._features(x8)
-        finally:
-            self.lib.pam_conv_option(1, old)
+        return self._features(x8)
 
     fuse_tail = True            # layer1: conv3 + residual + next conv1 of every Bottleneck in one launch (csrc/pam_pw.hip)
     tail_cfg = 0                # its wave-tile size (0 = automatic)

@@ -171,3 +171,61 @@ def test_grouped_fuse_launches_equal_single(eng):
         ref = eng.upsample_add(base, terms, sh, relu) if terms else torch.relu(base)
         torch.cuda.synchronize()
         assert torch.equal(o, ref)
+
+
+# ---- the resident-weights form (csrc/pam_block2.hip, C = 48) ---------------------------------------------------------------------
+CASES2 = [
+    # n, h, w, tile (None = the library's choice)
+    (2, 96, 72, None),
+    (20, 96, 72, None),          # the bench workload: 16 x 36 tiles, 240 items
+    (20, 96, 72, (24, 24)),
+    (3, 96, 72, (8, 18)),        # small tiles: the 3- / 2-M-tile instantiations
+    (2, 50, 72, (16, 36)),       # ragged last tile row
+    (2, 96, 70, (16, 36)),       # ragged last tile column
+    (1, 64, 48, None),           # 256 x 192 crops
+    (3, 7, 5, None),             # tiny image: one item, mostly junk slots
+    (2, 33, 41, (11, 13)),       # nothing divides anything
+    (28, 96, 72, None),          # a view-sharded Panoptic rank: two rounds of workgroups
+]
+
+
+@pytest.mark.parametrize('case', CASES2)
+def test_block2_vs_torch_and_ring_kernel(eng, case):
+    from pam import hrnet_hip
+    n, h, w, tile = case
+    c, dev = 48, eng.device
+    c1, c2 = make_block(c, 200 + h)
+    g = torch.Generator().manual_seed(11 + n + w)
+    x = torch.randn((n, c, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    op = hrnet_hip.PackedBlock(c1, c2, dev)
+    y = eng.basic_block2(op, x, tile)
+    torch.cuda.synchronize()
+    ref = torch_block(x, c1, c2)
+    err = (y.float() - ref).abs()
+    tol = 2e-2 + 1e-2 * ref.abs()
+    assert bool((err <= tol).all()), (case, float(err.max()), float((err / tol).max()))
+    assert float(err.mean()) < 2e-3, float(err.mean())
+    # the ring kernel and the two-launch path walk K in the same order: bit-identical
+    if eng.lib.pam_basic_block_rows(c, h, w, 8) > 0:
+        assert torch.equal(y, eng.basic_blocks([op], [x], 8)[0])
+    p1, p2 = hrnet_hip.PackedConv(c1, dev), hrnet_hip.PackedConv(c2, dev)
+    u = eng.conv(p2, eng.conv(p1, x, relu=True), res=x, relu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y, u)
+
+
+def test_block2_tile_choice_and_limits(eng):
+    import ctypes as C
+    t = (C.c_int32 * 2)()
+    assert eng.lib.pam_basic_block2_tile(48, 20, 96, 72, t) == 0
+    tr, tc = int(t[0]), int(t[1])
+    assert 20 * -(-96 // tr) * -(-72 // tc) <= 256 and (tr + 4) * (tc + 4) <= 800       # one round of workgroups at 20 crops
+    assert eng.lib.pam_basic_block2_tile(96, 20, 48, 36, t) != 0                          # 96 channels: the weights do not fit
+    x = torch.zeros((1, 48, 8, 8), dtype=torch.bfloat16, device=eng.device).contiguous(memory_format=torch.channels_last)
+    y = torch.empty_like(x)
+    w = torch.zeros(1024 + 2 * 14 * 48 * 64, dtype=torch.uint8, device=eng.device)
+    st = C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream)
+    rc = eng.lib.pam_basic_block2_nhwc_bf16(st, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(y.data_ptr()), 1, 8, 8, 48, 40, 40)
+    assert rc != 0                                                                         # tile beyond the LDS budget
+    rc = eng.lib.pam_basic_block2_nhwc_bf16(st, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(x.data_ptr()), 1, 8, 8, 48, 0, 0)
+    assert rc != 0                                                                         # in place

@@ -205,9 +205,10 @@ def test_leaky_layer_of_a_streamed_shape_takes_the_classic_kernel():
     assert e.lib.pam_conv_last_kernel() == 2                           # k_conv3x3s
 
 
+@pytest.mark.parametrize('slab', [48, 96])
 @pytest.mark.parametrize('shape', [(20, 48, 36), (2, 25, 18), (3, 7, 5), (2, 50, 30)])
-def test_streamed_kernel_for_the_96_channel_branch_behind_its_option(eng, shape):
-    """pam_conv_option(PAM_CONV_OPT_C96_STREAMED): 96 -> 96 3x3 layers on k_conv3x3s with 48-channel slabs (off by default) vs torch fp32."""
+def test_streamed_kernel_for_the_96_channel_branch(eng, shape, slab):
+    """96 -> 96 3x3 layers on k_conv3x3s with slabs of 48 or 96 output channels (the executor's c96_slab; off by default) vs torch fp32."""
     from pam import _lib, hrnet_hip
     n, h, w = shape
     lib = _lib.load()
@@ -221,15 +222,13 @@ def test_streamed_kernel_for_the_96_channel_branch_behind_its_option(eng, shape)
     res = torch.randn((n, 96, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
     e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
     e.lib = lib; e.device = dev; e.tile_cfg = -1
-    assert lib.pam_conv3x3_layout(h, w, 96, 96) == 0
-    old = lib.pam_conv_option(1, 1)
-    try:
-        assert lib.pam_conv3x3_layout(h, w, 96, 96) == 48
-        op = hrnet_hip.PackedConv(conv, dev)
-        y = e.conv(op, x, res=res, relu=True)
-        assert lib.pam_conv_last_kernel() == 2            # PAM_CONV_KERNEL_3X3S
-    finally:
-        lib.pam_conv_option(1, old)
+    assert lib.pam_conv3x3_layout(h, w, 96, 96) == 0 and lib.pam_conv3x3_layout_ex(h, w, 96, 96, slab) == slab
+    op = hrnet_hip.PackedConv(conv, dev)
+    y0 = e.conv(op, x, res=res, relu=True)
+    assert lib.pam_conv_last_kernel() == 1                # default: k_conv3x3
+    e.c96_slab = slab
+    y = e.conv(op, x, res=res, relu=True)
+    assert lib.pam_conv_last_kernel() == 2                # PAM_CONV_KERNEL_3X3S
     ref = torch.relu(F.conv2d(x.float(), conv.weight.detach().to(torch.bfloat16).float().to(dev), conv.bias.detach().to(dev), 1, 1) + res.float())
     torch.cuda.synchronize()
     err = (y.float() - ref).abs()

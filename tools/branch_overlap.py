@@ -8,8 +8,12 @@ import pam
 from pam import hrnet
 dev = torch.device('cuda:0')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+flags = sys.argv[2:]            # block2 (resident-weights 48-channel block), c96 (streamed 96-channel branch), unfused
 net = hrnet.HRNetPose(48, 17, None, use_graph=False, backend='hip')
 hip = net.hip
+hip.block2 = 'block2' in flags
+hip.fuse_blocks = not ('unfused' in flags or hip.block2)
+hip.c96_slab = 96 if 'c96w' in flags else (48 if 'c96' in flags else 0)
 mod = hip.stage4[0]
 shapes = [(48, 96, 72), (96, 48, 36), (192, 24, 18), (384, 12, 9)]
 xs = [torch.randn((n, c, h, w), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for c, h, w in shapes]
@@ -28,8 +32,7 @@ def run(subset):
             if b == 0 and hip.fuse_blocks:
                 for k in range(4): x = hip.basic_blocks([mod['fused'][0][k]], [x], hip.fuse_waves)[0]
             else:
-                for c1, c2 in mod['branches'][b]:
-                    y = hip.conv(c1, x, relu=True); x = hip.conv(c2, y, res=x, relu=True)
+                x = hip._branch_blocks(mod, b, mod['branches'][b], x)
     for st in hip.side: cur.wait_stream(st)
 
 def timeit(subset, iters=20):
