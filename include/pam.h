@@ -267,14 +267,22 @@ int pam_basic_block_nhwc_bf16(void* stream, int n_branches, const PamBlockDesc* 
  * the items at about half the cost each, C = 48 / 96) -- a packing choice for grouped launches, same results */
 int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* blocks, int waves);
 
-/* ---- the same BasicBlock with BOTH weight sets resident in LDS (csrc/pam_block2.hip; C = 48 only: 2 x 42 KB of weights beside a
- * 75 KB input tile).  2-D tiles of tile_rows x tile_cols output positions, one 512-thread workgroup each; no barrier inside the K
- * loops.  pam_basic_block2_tile writes the {rows, cols} the library would pick for N x H x W (whole rounds of 256 workgroups first,
- * then the fewest M tiles per SIMD); tile_rows / tile_cols <= 0 in the launch = that choice.  Limits: (rows + 4)(cols + 4) <= 800,
- * (rows + 2)(cols + 4) <= 768, rows (cols + 2) <= 640.
- * wpack (86 016 + 1 024 bytes): [float32 bias: conv1's 48, conv2's 48, zero padding to 1 KiB][conv1's 14 k-step images][conv2's 14],
- * a k-step image = [48 rows][64 bytes] exactly as pam_basic_block_nhwc_bf16's w_img for C = 48 (row permutation and piece swizzle
- * above).  Results are bit-identical to pam_basic_block_nhwc_bf16's (same K order per output element).  in != out. */
+/* ---- the same BasicBlock as ONE launch per tensor with 2-D items of tile_rows x tile_cols output positions (csrc/pam_block2.hip), all
+ * operands fetched by LDS-DMA.  pam_basic_block2_tile writes the {rows, cols} the library would pick for N x H x W (whole rounds of 256
+ * workgroups first, then the least work per item); tile_rows / tile_cols <= 0 in the launch = that choice.  in != out.
+ * C = 48 (k_bblock2_48): BOTH weight sets resident in LDS beside a 75 KB input tile, no barrier inside the K loops.  Limits:
+ *   (rows + 4)(cols + 4) <= 800, (rows + 2)(cols + 4) <= 768, rows (cols + 2) <= 640.
+ *   wpack (1 024 + 86 016 bytes): [float32 bias: conv1's 48, conv2's 48, zero padding to 1 KiB][conv1's 14 k-step images][conv2's 14]; a
+ *   k-step image = [48 rows][64 bytes] as pam_basic_block_nhwc_bf16's w_img for C = 48 except for the row -> channel rule: row
+ *   j*16 + q = output channel 8*(q >> 2) + 4*j + (q & 3) for j < 2 and 32 + 4*(q >> 2) + (q & 3) for j = 2.  Results are
+ *   bit-identical to pam_basic_block_nhwc_bf16's and to two pam_conv2d_nhwc_bf16 calls (same K order per output element).
+ * C = 96 (k_bblock2_96<3,2> / <5,4>): the input tile resident (chunk-major, 3 x 32 channels), the weights of both convolutions
+ *   streamed through a ring of six k-step images.  Limits: (rows + 4)(cols + 4) <= 640, (rows + 2)(cols + 4) <= 640, rows (cols + 2)
+ *   <= 512 (half of the latter two for the small instantiation, which the picker prefers while it fills the chip).
+ *   wpack (1 024 + 331 776 bytes): [float32 bias 96 + 96, padded to 1 KiB][54 k-step images of [96 rows][64 bytes]] in the order (conv,
+ *   chunk of 32 input channels, tap); row j*16 + q = output channel 24*(q >> 2) + 4*j + (q & 3); physical 16-byte piece p of row r
+ *   holds the chunk's input channels 8*(p ^ ((r >> 1) & 2)) .. + 7.  The residual enters the sum before the products (as in the
+ *   streamed convolution kernel): equal to the two-launch path to within the last bf16 bit. */
 int pam_basic_block2_tile(int C, int N, int H, int W, int32_t* out2);
 int pam_basic_block2_nhwc_bf16(void* stream, const void* in, const void* wpack, void* out, int N, int H, int W, int C,
                                int tile_rows, int tile_cols);

@@ -74,10 +74,10 @@ struct BB2Args {
 __device__ __attribute__((aligned(64))) const uint32_t g_bb2_zero[16] = {0};
 
 __device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }   // exact for x < 2^16
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(uint32_t, v);
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {     // one v_cvt_pk_bf16_f32 (RNE); the cast form compiles to two converts + a permute
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {           // bf16 is sign-magnitude: max(int16, 0) clears the negatives
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
@@ -223,10 +223,11 @@ __global__ __launch_bounds__(512) void k_bblock2_48(BB2Args a) {
         const int iy = ty0 - 1 + r1, ix = tx0 - 1 + c1;
         const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         maddr[i] = (r1 < a.TR + 2 && c1 < a.TC + 2) ? (r1 * PWi + c1) * PA : -1;
+        const uint32_t keep = ok ? 0xffffffffu : 0u;       // a mask, not a branch per value
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            mid[i][2 * j] = ok ? relu_bf16x2(pack_bf16x2(acc[i][j][0], acc[i][j][1])) : 0u;
-            mid[i][2 * j + 1] = ok ? relu_bf16x2(pack_bf16x2(acc[i][j][2], acc[i][j][3])) : 0u;
+            mid[i][2 * j] = relu_bf16x2(pack_bf16x2(acc[i][j][0], acc[i][j][1])) & keep;
+            mid[i][2 * j + 1] = relu_bf16x2(pack_bf16x2(acc[i][j][2], acc[i][j][3])) & keep;
         }
     }
     __syncthreads();                                     // every wave is done reading X (and all DMAs have landed: W2 is complete)
@@ -288,6 +289,289 @@ __global__ __launch_bounds__(512) void k_bblock2_48(BB2Args a) {
     BB2_STAMP(7);
 }
 
+// ====================================================================================================================================
+// k_bblock2_96: the same fused block for the 96-channel branch (48 x 36 maps).  Its weights (2 x 166 KB) do not fit LDS, so they STREAM
+// through a ring of six k-step images (96 rows x 64 B = 6 KB each) while the input tile stays resident:
+//   LDS = [X tile, chunk-major: 3 chunks of 32 channels x XSP slots x 64 B, 16-byte pieces swizzled as k_conv3x3s's][bias 1 KB][ring 36 KB]
+// Why it pays although a fused 96-channel item streams 332 KB of weights: the unfused layer is LDS-fill-bound (every workgroup of
+// k_conv3x3s pulls its weight slab AND its patch for 300 pixels x 48 channels: 156 KB for 25 MFLOP); here one item is up to 12 rows x 36
+// columns x all 96 channels x both convolutions (200 MFLOP for 450 KB): the K loops are MFMA-bound, a block costs half the CU-time, one
+// launch instead of two, and the intermediate never leaves LDS.
+//   * K = (chunk, tap) -- chunk-major, 27 k-steps of 32 per convolution: conv1 starts when the FIRST 32-channel chunk of X has landed.
+//   * all eight waves multiply (5 x 6 accumulator tiles for conv1, 4 x 6 for conv2: 11 / 10 fragment reads per 30 / 24 MFMAs); waves 0-3
+//     also feed the ring (3 DMA pieces each per two k-steps), waves 4-7 fetch X (all three chunks up front, 30 pieces each, counted vmcnt).
+//   * one raw s_barrier per TWO k-steps (top of every odd k-step s = 2p + 1): everybody is done reading k-steps <= s, so the pair
+//     (2p, 2p + 1) is refilled with (2p + 6, 2p + 7); the pair (2p + 2, 2p + 3) has landed (vmcnt(3): only the youngest pair is in flight).
+//   * the weight fragments are single-buffered: the MFMAs of a k-step run N tile by N tile and fragment j of the next k-step is read right
+//     behind the 5 MFMAs that used fragment j of this one; the pixel fragments are double-buffered.  (Register plan: 120 accumulators +
+//     24 + 40 fragment registers; pinning the issue order with sched_group_barrier made hipcc spill 114 registers, plain program order
+//     with one sched_barrier per k-step allocates 240 with no scratch.)
+//   * the residual is read from X before the intermediate overwrites it and folded into conv2's accumulators (as k_conv3x3s does).
+// ====================================================================================================================================
+constexpr int B96_NW = 8;                  // waves per workgroup (two per SIMD)
+constexpr int B96_NS = 27;                 // k-steps per convolution
+constexpr int B96_KIMG = 96 * 64;          // one k-step's weight image
+constexpr int B96_RING = 6;                // ring slots
+// M tiles per wave (conv1, conv2) are template parameters: <5, 4> takes items of up to 12 x 36 positions, <3, 2> half-size items
+constexpr int B96_TST = B96_NW * 16 * 64;  // byte distance between a wave's consecutive M tiles inside a chunk image (tile = wave + 4 i)
+constexpr int B96_NPW = 10;                // X pieces (16 slots x 64 B) per chunk and loader wave (waves 4-7): XSP <= 640 slots
+constexpr int B96_XSP_MAX = 16 * 4 * B96_NPW;
+
+struct BB96Args {
+    const uint16_t* in; const char* wpack; uint16_t* out;
+    int N, H, W, TR, TC, tiles_y, tiles_x, nitems, xsp;
+    float inv_pwx, inv_pwi;
+#ifdef PAM_DIAG
+    unsigned long long* stamps;
+#endif
+};
+__device__ __attribute__((aligned(256))) const uint32_t g_bb96_zero[64] = {0};
+
+#define B96_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <int MT1, int MT2>
+__global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bx;
+    { const int v = blockIdx.x, q = a.nitems >> 3, r = a.nitems & 7, xcd = v & 7, loc = v >> 3; bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc; }
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int n = bx / per_img, trem = bx - n * per_img, tyi = trem / a.tiles_x, txi = trem - tyi * a.tiles_x;
+    const int ty0 = tyi * a.TR, tx0 = txi * a.TC;
+    const int PWx = a.TC + 4, PWi = a.TC + 2, XS = (a.TR + 4) * PWx;
+    const unsigned CS = (unsigned)a.xsp * 64u;           // bytes of one chunk image
+    char* Xb = smem;
+    char* Bs = smem + 3 * CS;
+    char* ring = Bs + 1024;
+#ifdef PAM_DIAG
+    const int stamp_wave = wave;
+#define B96_STAMP(k) do { if (a.stamps && lane == 0) a.stamps[((size_t)blockIdx.x * 8 + stamp_wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define B96_STAMP(k) do { } while (0)
+#endif
+    B96_STAMP(0);
+
+    // ---- DMA roles -------------------------------------------------------------------------------------------------------------------
+    const char* wsrc = a.wpack + lane * 16;
+    auto wdma_pair = [&](int q) {                        // k-steps 2q, 2q + 1 of the 54-step stream -> ring slots (2q % 6, + 1): waves 0-3, 3 pieces each
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int e = wave + 4 * k;
+            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + 1024 + (size_t)(2 * q) * B96_KIMG + e * 1024),
+                                             (lds_void*)(ring + ((2 * q) % B96_RING) * B96_KIMG + e * 1024), 16, 0, 0);
+        }
+    };
+    // X, chunk-major: piece P of a chunk image = slots 16 P .. 16 P + 15, lane -> slot 16 P + (lane >> 2), physical piece lane & 3 holding
+    // logical piece (lane & 3) ^ ((slot >> 1) & 2).  The pixel address is the same for the three chunks (+ 64 bytes per chunk).
+    const int lw = wave & 3, np = a.xsp >> 4;
+    const char* psrc[B96_NPW];
+    auto xdma_chunk = [&](int c) {
+#pragma unroll
+        for (int m = 0; m < B96_NPW; ++m) {
+            const int P = min(lw + 4 * m, np - 1);       // a wave short of a piece re-sends the last one (keeps the vmcnt counts fixed)
+            __builtin_amdgcn_global_load_lds((glb_void*)(psrc[m] + 64 * c), (lds_void*)(Xb + c * CS + P * 1024), 16, 0, 0);
+        }
+    };
+    if (wave < 4) {
+        if (wave == 0) __builtin_amdgcn_global_load_lds((glb_void*)wsrc, (lds_void*)Bs, 16, 0, 0);     // bias
+        wdma_pair(0); wdma_pair(1); wdma_pair(2);
+    } else {
+        const char* img = (const char*)a.in + (size_t)n * a.H * a.W * 192;
+#pragma unroll
+        for (int m = 0; m < B96_NPW; ++m) {
+            const int P = min(lw + 4 * m, np - 1);
+            const int slot = 16 * P + (lane >> 2);
+            const int gl = (lane & 3) ^ ((slot >> 1) & 2);
+            const int row = fdiv_small(slot, a.inv_pwx), col = slot - row * PWx;
+            const int iy = ty0 - 2 + row, ix = tx0 - 2 + col;
+            const bool ok = slot < XS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            psrc[m] = ok ? img + ((size_t)iy * a.W + ix) * 192 + gl * 16 : (const char*)g_bb96_zero;
+        }
+        xdma_chunk(0);                                   // the other two chunks: behind the first barrier (they land under the first k-steps)
+    }
+
+    // this lane's fragment addresses.  B (activations): slot s of a chunk image at s * 64, logical piece g at g ^ ((s >> 1) & 2); M tile i of
+    // the wave = slots (wave + 8 i) * 16 ..: + i * 8 KiB with the same swizzle (bit 2 of the slot unchanged).  A (weights): row j * 16 + l15.
+    auto mk_aoff = [&](int PW, unsigned (&aoff)[9]) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int sl = wave * 16 + l15 + (t / 3) * PW + (t % 3);
+            aoff[t] = (unsigned)(sl * 64 + ((g ^ ((sl >> 1) & 2)) << 4));
+        }
+    };
+    unsigned aoff[9];
+    mk_aoff(PWx, aoff);
+    const char* wl = ring + l15 * 64 + ((g ^ ((lane >> 1) & 2)) << 4);
+    const float* bias = (const float*)Bs;
+
+    B96_STAMP(1);
+    if (wave < 4) B96_VM(6); else B96_VM(0);             // pair 0 of the ring (and the bias) / chunk 0 of X have landed ...
+    asm volatile("s_barrier" ::: "memory");              // ... everybody's
+    if (wave >= 4) { xdma_chunk(1); xdma_chunk(2); }
+    B96_STAMP(2);
+
+    f32x4 acc[MT1][6];
+    // One convolution: k-steps S0 .. S0 + 26 of the weight stream, MT M tiles per wave.
+    auto conv = [&](auto MTC, auto S0C) {
+        constexpr int MT = decltype(MTC)::value, S0 = decltype(S0C)::value;
+        bf16x8 af[6], bf[2][MT];
+        auto wrow = [&](int s, int j) { return *(const bf16x8*)(wl + (s % B96_RING) * B96_KIMG + j * 1024); };
+        auto xfrag = [&](int s, int i) {
+            const int st = s - S0, c = st / 9, t = st - 9 * c;
+            return *(const bf16x8*)(Xb + c * CS + aoff[t] + i * B96_TST);
+        };
+#pragma unroll
+        for (int j = 0; j < 6; ++j) af[j] = wrow(S0, j);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) bf[0][i] = xfrag(S0, i);
+#pragma unroll
+        for (int st = 0; st < B96_NS; ++st) {
+            const int s = S0 + st, cur = st & 1, nxt = cur ^ 1;
+            const bool more = st + 1 < B96_NS;
+            if (s & 1) {                                 // top of an odd k-step: the ring's barrier p = (s - 1) / 2
+                const int p = (s - 1) >> 1;
+                __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of k-step s (the youngest it has issued) are done
+                if (wave < 4) { if (p + 2 < B96_NS) B96_VM(3); else B96_VM(0); }     // pair p + 1 has landed; only pair p + 2 may still fly
+                else if (S0 == 0 && p == 3) B96_VM(B96_NPW);                        // chunk 1 of X: first read in k-step 8 (for k-step 9)
+                else if (S0 == 0 && p == 8) B96_VM(0);                              // chunk 2
+                asm volatile("s_barrier" ::: "memory");
+                if (wave < 4 && p + 3 < B96_NS) wdma_pair(p + 3);
+            }
+            constexpr int BPG = (MT + 5) / 6;            // pixel-fragment reads of the next k-step per N-tile group
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[j]), __builtin_bit_cast(bf16x8_t, bf[cur][i]), acc[i][j], 0, 0, 0);
+                if (more) {
+                    af[j] = wrow(s + 1, j);
+#pragma unroll
+                    for (int k = 0; k < BPG; ++k)
+                        if (j * BPG + k < MT) bf[nxt][j * BPG + k] = xfrag(s + 1, j * BPG + k);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- conv1 -------------------------------------------------------------------------------------------------------------------
+    // a lane's 24 output channels: 24 g + 4 j + r (N tile j, accumulator element r)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const f32x4 b4 = *(const f32x4*)(bias + 24 * g + 4 * j);
+#pragma unroll
+        for (int i = 0; i < MT1; ++i) acc[i][j] = b4;
+    }
+    conv(std::integral_constant<int, MT1>{}, std::integral_constant<int, 0>{});
+    B96_STAMP(3);
+
+    // intermediate = ReLU(conv1 + b1) as bf16: three 16-byte pieces per lane and tile (channels 24 g + 8 m .. + 7 -> chunk (24 g + 8 m) / 32,
+    // logical piece ((24 g + 8 m) % 32) / 8), packed and addressed before the barrier, written after it
+    uint32_t mid[MT1][12];
+    int maddr[MT1];
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) {
+        const int p = (wave + B96_NW * i) * 16 + l15;
+        const int r1 = fdiv_small(p, a.inv_pwx), c1 = p - r1 * PWx;
+        const int iy = ty0 - 1 + r1, ix = tx0 - 1 + c1;
+        const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const int si = r1 * PWi + c1;
+        maddr[i] = (r1 < a.TR + 2 && c1 < a.TC + 2) ? si : -1;
+        const uint32_t keep = ok ? 0xffffffffu : 0u;       // a mask, not a branch per value
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            mid[i][2 * j] = relu_bf16x2(pack_bf16x2(acc[i][j][0], acc[i][j][1])) & keep;
+            mid[i][2 * j + 1] = relu_bf16x2(pack_bf16x2(acc[i][j][2], acc[i][j][3])) & keep;
+        }
+    }
+    // residual = centre of X at this lane's conv2 output pixels, folded into conv2's accumulators (bias + residual, then the products)
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) {
+        const int q = (wave + B96_NW * i) * 16 + l15;
+        const int r2 = fdiv_small(q, a.inv_pwi), c2 = q - r2 * PWi;
+        const bool ok = r2 < a.TR && c2 < a.TC;
+        const int sx = ok ? (r2 + 2) * PWx + c2 + 2 : 0;
+        const unsigned sw = (unsigned)((sx >> 1) & 2);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int ch = 24 * g + 8 * m;
+            const u32x4 v = *(const u32x4*)(Xb + (ch >> 5) * CS + sx * 64 + ((((ch & 31) >> 3) ^ sw) << 4));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 b4 = *(const f32x4*)(bias + 96 + ch + 4 * h);
+                acc[i][2 * m + h][0] = b4[0] + __builtin_bit_cast(float, v[2 * h] << 16);
+                acc[i][2 * m + h][1] = b4[1] + __builtin_bit_cast(float, v[2 * h] & 0xffff0000u);
+                acc[i][2 * m + h][2] = b4[2] + __builtin_bit_cast(float, v[2 * h + 1] << 16);
+                acc[i][2 * m + h][3] = b4[3] + __builtin_bit_cast(float, v[2 * h + 1] & 0xffff0000u);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");              // every wave is done reading X (ring DMAs stay in flight: raw barrier)
+    B96_STAMP(4);
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) {
+        if (maddr[i] < 0) continue;
+        const unsigned sw = (unsigned)((maddr[i] >> 1) & 2);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int ch = 24 * g + 8 * m;
+            *(u32x4*)(Xb + (ch >> 5) * CS + maddr[i] * 64 + ((((ch & 31) >> 3) ^ sw) << 4)) = (u32x4){mid[i][4 * m], mid[i][4 * m + 1], mid[i][4 * m + 2], mid[i][4 * m + 3]};
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");              // the intermediate is visible
+    B96_STAMP(5);
+
+    // ---- conv2 + epilogue ------------------------------------------------------------------------------------------------------------
+    mk_aoff(PWi, aoff);
+    conv(std::integral_constant<int, MT2>{}, std::integral_constant<int, B96_NS>{});
+    B96_STAMP(6);
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) {
+        const int q = (wave + B96_NW * i) * 16 + l15;
+        const int r2 = fdiv_small(q, a.inv_pwi), c2 = q - r2 * PWi;
+        const int oy = ty0 + r2, ox = tx0 + c2;
+        if (r2 < a.TR && c2 < a.TC && oy < a.H && ox < a.W) {
+            uint16_t* d = a.out + (((size_t)n * a.H + oy) * a.W + ox) * 96 + 24 * g;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                *(u32x4*)(d + 8 * m) = (u32x4){relu_bf16x2(pack_bf16x2(acc[i][2 * m][0], acc[i][2 * m][1])), relu_bf16x2(pack_bf16x2(acc[i][2 * m][2], acc[i][2 * m][3])),
+                                               relu_bf16x2(pack_bf16x2(acc[i][2 * m + 1][0], acc[i][2 * m + 1][1])), relu_bf16x2(pack_bf16x2(acc[i][2 * m + 1][2], acc[i][2 * m + 1][3]))};
+        }
+    }
+    B96_STAMP(7);
+}
+
+// instantiated (M tiles per wave for conv1, conv2) pairs, smallest first
+static const int kB96Inst[2][2] = {{3, 2}, {5, 4}};
+int b96_inst(int s1, int s2) {
+    for (int k = 0; k < 2; ++k)
+        if (s1 <= 16 * B96_NW * kB96Inst[k][0] && s2 <= 16 * B96_NW * kB96Inst[k][1]) return k;
+    return -1;
+}
+// Tile for N x H x W: every item streams all the weights and multiplies the instantiated tile counts whatever it needs of them; the
+// cost of a launch = rounds of 256 workgroups x (fixed part + MFMA time of the instantiation), ties -> less halo.
+bool pick_tile96(int N, int H, int W, int& TR, int& TC) {
+    static thread_local int cN = 0, cH = 0, cW = 0, cTR = 0, cTC = 0;
+    if (N == cN && H == cH && W == cW) { TR = cTR; TC = cTC; return true; }
+    long best = -1;
+    for (int tr = 1; tr <= H; ++tr)
+        for (int tc = 1; tc <= W; ++tc) {
+            const int s1 = (tr + 2) * (tc + 4), s2 = tr * (tc + 2), xs = (tr + 4) * (tc + 4);
+            const int k = b96_inst(s1, s2);
+            if (k < 0 || (xs + 15) / 16 * 16 > B96_XSP_MAX) continue;
+            const long items = (long)N * ((H + tr - 1) / tr) * ((W + tc - 1) / tc);
+            const long per = 6 + kB96Inst[k][0] + kB96Inst[k][1];
+            const long cost = ((items + 255) / 256) * per * (1L << 32) + items * (1L << 16) + (long)s1 + s2;
+            if (best < 0 || cost < best) { best = cost; TR = tr; TC = tc; }
+        }
+    if (best < 0) return false;
+    cN = N; cH = H; cW = W; cTR = TR; cTC = TC;
+    return true;
+}
+
 // Tile of the resident-weights block for an N x H x W tensor: the (TR, TC) that minimises rounds of workgroups x time of an item.
 // An item's time: a fixed prologue (the X tile and the first weights must land before the first MFMA: ~8 M tiles' worth) plus, per
 // convolution, the M tiles of the busiest SIMD (tile t -> wave t % 8 -> SIMD t % 4; a wave multiplies the instantiated count that
@@ -322,16 +606,50 @@ bool pick_tile(int N, int H, int W, int& TR, int& TC) {
 }  // namespace
 
 extern "C" int pam_basic_block2_tile(int C, int N, int H, int W, int32_t* out2) {
-    if (C != 48 || N < 1 || H < 1 || W < 1 || !out2) return PAM_E_ARG;
+    if ((C != 48 && C != 96) || N < 1 || H < 1 || W < 1 || !out2) return PAM_E_ARG;
     int tr = 0, tc = 0;
-    if (!pick_tile(N, H, W, tr, tc)) return PAM_E_ARG;
+    if (!(C == 48 ? pick_tile(N, H, W, tr, tc) : pick_tile96(N, H, W, tr, tc))) return PAM_E_ARG;
     out2[0] = tr; out2[1] = tc;
     return PAM_OK;
 }
 
+static int launch_bb96(void* stream, const void* in, const void* wpack, void* out, int N, int H, int W, int tile_rows, int tile_cols) {
+    BB96Args a;
+    a.in = (const uint16_t*)in; a.wpack = (const char*)wpack; a.out = (uint16_t*)out;
+    a.N = N; a.H = H; a.W = W;
+    if (tile_rows > 0 && tile_cols > 0) { a.TR = tile_rows; a.TC = tile_cols; }
+    else if (!pick_tile96(N, H, W, a.TR, a.TC)) return PAM_E_ARG;
+    a.xsp = ((a.TR + 4) * (a.TC + 4) + 15) / 16 * 16;
+    const int inst = b96_inst((a.TR + 2) * (a.TC + 4), a.TR * (a.TC + 2));
+    if (inst < 0 || a.xsp > B96_XSP_MAX) return PAM_E_ARG;
+    a.tiles_y = (H + a.TR - 1) / a.TR; a.tiles_x = (W + a.TC - 1) / a.TC;
+    a.nitems = N * a.tiles_y * a.tiles_x;
+    a.inv_pwx = 1.0f / (float)(a.TC + 4); a.inv_pwi = 1.0f / (float)(a.TC + 2);
+    // junk M tiles of conv1 read up to 2 rows + 2 slots past the last real slot of a chunk image: keep that inside the allocation
+    size_t lds = (size_t)3 * a.xsp * 64 + 1024 + (size_t)B96_RING * B96_KIMG;
+    const size_t reach = (size_t)2 * a.xsp * 64 + (size_t)(16 * B96_NW * kB96Inst[inst][0] + 2 * (a.TC + 4) + 3) * 64;
+    if (reach > lds) lds = reach;
+    if (lds > 160 * 1024) return PAM_E_ARG;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return PAM_E_HIP;
+    static unsigned long long attr_set = 0;
+    if (dev < 64 && !((attr_set >> dev) & 1)) {
+        if (hipFuncSetAttribute((const void*)k_bblock2_96<5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_bblock2_96<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PAM_E_HIP;
+        attr_set |= 1ull << dev;
+    }
+#ifdef PAM_DIAG
+    a.stamps = g_bb2_stamps;
+#endif
+    if (inst == 0) pam_launch(k_bblock2_96<3, 2>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    else pam_launch(k_bblock2_96<5, 4>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
 extern "C" int pam_basic_block2_nhwc_bf16(void* stream, const void* in, const void* wpack, void* out, int N, int H, int W, int C, int tile_rows, int tile_cols) {
-    if (C != 48 || !in || !wpack || !out || in == out || N < 1 || H < 1 || W < 1) return PAM_E_ARG;
+    if ((C != 48 && C != 96) || !in || !wpack || !out || in == out || N < 1 || H < 1 || W < 1) return PAM_E_ARG;
     if ((size_t)N * H * W * C * 2 >= (1ull << 31)) return PAM_E_ARG;
+    if (C == 96) return launch_bb96(stream, in, wpack, out, N, H, W, tile_rows, tile_cols);
     BB2Args a;
     a.in = (const uint16_t*)in; a.wpack = (const char*)wpack; a.out = (uint16_t*)out;
     a.N = N; a.H = H; a.W = W;

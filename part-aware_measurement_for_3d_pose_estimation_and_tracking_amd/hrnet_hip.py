@@ -156,6 +156,21 @@ class PackedBlock(object):
             head[:2 * c] = self.bias.reshape(-1).cpu()
             self.wpack = torch.cat([head.view(torch.uint8), images(chan2).to(torch.bfloat16).reshape(-1).view(torch.uint8)]).to(device).contiguous()
             assert self.wpack.numel() == 1024 + 2 * 14 * 48 * 64
+        elif c == 96:
+            # k_bblock2_96 streams k-step images [96 rows][4 pieces][8] in the order (conv, chunk of 32 input channels, tap); row j * 16 + q
+            # = output channel 24 * (q >> 2) + 4 * j + (q & 3) (a lane ends with 24 contiguous channels), physical piece p of row r holds the
+            # chunk's input channels 8 * (p ^ ((r >> 1) & 2)) .. + 7
+            chan96 = 24 * ((rows % 16) >> 2) + 4 * (rows // 16) + (rows & 3)
+            src96 = torch.arange(4)[None, :] ^ ((rows >> 1) & 2)[:, None]
+            imgs = []
+            for conv in (conv1, conv2):
+                w = conv.weight.detach().float().permute(0, 2, 3, 1)[chan96]                  # [row][ky][kx][cin]
+                w = w.reshape(c, 9, 3, 4, 8).permute(2, 1, 0, 3, 4)                           # [chunk][tap][row][piece][8]
+                imgs.append(torch.gather(w, 3, src96[None, None, :, :, None].expand(3, 9, c, 4, 8)))
+            head = torch.zeros(256, dtype=torch.float32)
+            head[:2 * c] = self.bias.reshape(-1).cpu()
+            self.wpack = torch.cat([head.view(torch.uint8), torch.stack(imgs).to(torch.bfloat16).reshape(-1).view(torch.uint8)]).to(device).contiguous()
+            assert self.wpack.numel() == 1024 + 2 * 27 * 96 * 64
 
 
 class PackedTail(object):
@@ -337,13 +352,15 @@ class ConvEngine(object):
         if x.device.type == 'meta':
             return y
         assert x.is_contiguous(memory_format=torch.channels_last)
+        if tile is None and c == 96 and self.b96_tile:
+            tile = tuple(self.b96_tile)
         if tile is None:
-            tile = self._bb2_tiles.get((n, h, w))
+            tile = self._bb2_tiles.get((c, n, h, w))
             if tile is None:
                 t2 = (C.c_int32 * 2)()
                 if self.lib.pam_basic_block2_tile(c, n, h, w, t2) != 0:
                     raise _lib.PamError('no resident-weights block tile for %s' % (tuple(x.shape),))
-                tile = self._bb2_tiles[(n, h, w)] = (int(t2[0]), int(t2[1]))
+                tile = self._bb2_tiles[(c, n, h, w)] = (int(t2[0]), int(t2[1]))
         launch = lambda: self.lib.pam_basic_block2_nhwc_bf16(C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()),
                                                               C.c_void_p(op.wpack.data_ptr()), C.c_void_p(y.data_ptr()), n, h, w, c, tile[0], tile[1])
         rc = launch()
@@ -352,7 +369,8 @@ class ConvEngine(object):
         self._prof_add(x, 'k_bblock2 C=%d' % c, (n, h, w, c) + tuple(tile), nbytes, flops, launch)
         return y
 
-    _bb2_tiles = {}             # (N, H, W) -> the library's tile choice (pam_basic_block2_tile searches ~H x W candidates)
+    _bb2_tiles = {}             # (C, N, H, W) -> the library's tile choice (pam_basic_block2_tile searches ~H x W candidates)
+    b96_tile = None             # (rows, cols) of the 96-channel fused block's items instead of the library's choice (tuning)
 
     def pointwise64(self, op, x):
         """ReLU(conv1x1 64 -> 64 (x)) as a pure stream (k_pw1)."""
@@ -644,13 +662,14 @@ class HipHRNet(ConvEngine):
     # depends on how a crop count's tile counts quantise on 256 CUs -- interleaved A/B, one device, vs 'grouped': 20 crops 'streamed96'
     # -2.8 %, 'unfused' -0.4 %; 28 crops 0 / +1.1 %; 40 crops +2.2 / +1.3 %; 60 crops -0.6 / -2.9 %; 112 crops +4.1 %; 217 crops +6.6 %.
     CONFIGS = {
-        'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=False),      # branches 0 + 1 as one fused-BasicBlock launch per level
-        'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=False),     # one launch per convolution, 96-channel branch on k_conv3x3
-        'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=False),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
-        'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_slab=48, fuse_short=0, block2=False),   # branch 0 fused alone (ring kernel), branch 1 streamed
-        'resident48_streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=True),   # branch 0 on the resident-weights fused block
-        'resident48': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=True),
-        'resident48_wide96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=96, fuse_short=0, block2=True),         # ... 96-channel slabs: the patch is fetched once
+        'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=0),      # branches 0 + 1 as one fused-BasicBlock launch per level
+        'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=0),     # one launch per convolution, 96-channel branch on k_conv3x3
+        'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=0),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
+        'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_slab=48, fuse_short=0, block2=0),   # branch 0 fused alone (ring kernel), branch 1 streamed
+        'resident48_streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=1),   # branch 0 on the resident-weights fused block
+        'resident48': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=1),
+        'resident48_wide96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=96, fuse_short=0, block2=1),         # ... 96-channel slabs: the patch is fetched once
+        'fused48_fused96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=3),           # both fine branches on the new fused blocks
     }
     fuse_short = 0              # bit b: grouped branch b runs as "short" 4-row items (pam_basic_block_nhwc_bf16_ex, bits 4-7 of `waves`): meant to
                                 # pack the grouped launch better (360 items of 22-29 us on 256 CUs), measured SLOWER alone (47.7-47.9 vs 41.0 us
@@ -823,7 +842,8 @@ class HipHRNet(ConvEngine):
             self.stamp(tag)
 
     knock_out = 0               # diagnostics: bit b = skip the BasicBlocks of branch b (what would a free branch be worth)
-    block2 = False              # 48-channel branch: one resident-weights fused BasicBlock launch per block (csrc/pam_block2.hip)
+    block2 = 0                  # bit 0: 48-channel branch as one resident-weights fused BasicBlock launch per block (k_bblock2_48), bit 1: the
+                                # 96-channel branch on the streamed-weights fused block (k_bblock2_96) -- csrc/pam_block2.hip
 
     def _branch_blocks(self, mod, b, blocks, x):
         """The BasicBlocks of branch b that no grouped launch took, on the current stream."""
@@ -842,7 +862,7 @@ class HipHRNet(ConvEngine):
         def done():
             if b == 0 and self.multi_stream and not self.plan_rec and x.device.type == 'cuda' and any(self.stagger.get(nb, ())):
                 ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device)); self._b0_events.append(ev)
-        if self.block2 and blocks and fused is not None and fused[0].wpack is not None:
+        if self.block2 and blocks and fused is not None and fused[0].wpack is not None and (self.block2 & (1 if fused[0].c == 48 else 2)):
             for op in fused:
                 x = self.basic_block2(op, x); done()
             return x

@@ -220,7 +220,8 @@ def test_block2_tile_choice_and_limits(eng):
     assert eng.lib.pam_basic_block2_tile(48, 20, 96, 72, t) == 0
     tr, tc = int(t[0]), int(t[1])
     assert 20 * -(-96 // tr) * -(-72 // tc) <= 256 and (tr + 4) * (tc + 4) <= 800       # one round of workgroups at 20 crops
-    assert eng.lib.pam_basic_block2_tile(96, 20, 48, 36, t) != 0                          # 96 channels: the weights do not fit
+    assert eng.lib.pam_basic_block2_tile(96, 20, 48, 36, t) == 0 and (int(t[0]) + 4) * (int(t[1]) + 4) <= 640      # 96 channels: weights streamed
+    assert eng.lib.pam_basic_block2_tile(192, 20, 24, 18, t) != 0
     x = torch.zeros((1, 48, 8, 8), dtype=torch.bfloat16, device=eng.device).contiguous(memory_format=torch.channels_last)
     y = torch.empty_like(x)
     w = torch.zeros(1024 + 2 * 14 * 48 * 64, dtype=torch.uint8, device=eng.device)
@@ -229,3 +230,44 @@ def test_block2_tile_choice_and_limits(eng):
     assert rc != 0                                                                         # tile beyond the LDS budget
     rc = eng.lib.pam_basic_block2_nhwc_bf16(st, C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(x.data_ptr()), 1, 8, 8, 48, 0, 0)
     assert rc != 0                                                                         # in place
+
+
+CASES96 = [
+    # n, h, w, tile
+    (2, 48, 36, None),
+    (20, 48, 36, None),          # the bench workload: 12 x 36 tiles, 80 items
+    (20, 48, 36, (12, 18)),
+    (3, 48, 36, (6, 36)),
+    (2, 27, 36, (12, 36)),       # ragged last tile row
+    (2, 48, 34, (12, 18)),       # ragged last tile column
+    (2, 32, 24, None),           # 256 x 192 crops
+    (3, 7, 5, None),             # tiny image
+    (2, 21, 29, (7, 11)),
+    (28, 48, 36, None),
+]
+
+
+@pytest.mark.parametrize('case', CASES96)
+def test_block2_96_vs_torch_and_unfused(eng, case):
+    """The streamed-weights fused block of the 96-channel branch (k_bblock2_96) against the fp32 PyTorch block (intermediate rounded to
+    bf16 as the kernel stores it) and the two-launch path (same products; the residual enters the sum first, as in k_conv3x3s)."""
+    from pam import hrnet_hip
+    n, h, w, tile = case
+    c, dev = 96, eng.device
+    c1, c2 = make_block(c, 300 + h)
+    g = torch.Generator().manual_seed(13 + n + w)
+    x = torch.randn((n, c, h, w), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+    op = hrnet_hip.PackedBlock(c1, c2, dev)
+    y = eng.basic_block2(op, x, tile)
+    torch.cuda.synchronize()
+    ref = torch_block(x, c1, c2)
+    err = (y.float() - ref).abs()
+    tol = 2e-2 + 1e-2 * ref.abs()
+    assert bool((err <= tol).all()), (case, float(err.max()), float((err / tol).max()))
+    assert float(err.mean()) < 2e-3, float(err.mean())
+    p1, p2 = hrnet_hip.PackedConv(c1, dev), hrnet_hip.PackedConv(c2, dev)
+    u = eng.conv(p2, eng.conv(p1, x, relu=True), res=x, relu=True)
+    torch.cuda.synchronize()
+    d = (y.float() - u.float()).abs()
+    assert float(d.max()) <= 4e-2 + 1e-2 * float(u.float().abs().max()), float(d.max())
+    assert float((d > 0).float().mean()) < 0.05

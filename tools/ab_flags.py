@@ -26,6 +26,8 @@ for v in args.variants:
             form = val
         elif k.startswith('opt'):                        # library option, e.g. opt1=1 (PAM_CONV_OPT_C96_STREAMED); reset after the capture
             hip.lib.pam_conv_option(int(k[3:]), int(val)); opts.append(int(k[3:]))
+        elif k == 'b96_tile':                            # e.g. b96_tile=12x36
+            hip.b96_tile = tuple(int(q) for q in val.split('x'))
         elif k == 'stagger':                             # e.g. stagger=3:001/4:0012
             hip.stagger = {int(a): tuple(int(c) for c in b) for a, b in (q.split(':') for q in val.split('/'))}
         else:

@@ -18,6 +18,8 @@ net = hrnet.HRNetPose(48, 17, None, use_graph=False)
 hip = net.hip
 for kv in [q for q in args.spec.split(',') if q]:
     k, _, val = kv.partition('=')
+    if k == 'b96_tile':
+        hip.b96_tile = tuple(int(q) for q in val.split('x')); continue
     if k == 'stagger':                                   # e.g. stagger=3:001/4:0012
         hip.stagger = {int(a): tuple(int(c) for c in b) for a, b in (q.split(':') for q in val.split('/'))}; continue
     cur = getattr(hip, k)

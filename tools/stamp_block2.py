@@ -4,7 +4,7 @@ tool).  Builds a DIAGNOSTIC copy (-DPAM_DIAG [+ extra -D flags]) into /tmp and l
 import os, sys, argparse, subprocess, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument('--n', type=int, default=20); ap.add_argument('--defs', default=''); ap.add_argument('--tile', default='')
+ap = argparse.ArgumentParser(); ap.add_argument('--n', type=int, default=20); ap.add_argument('--defs', default=''); ap.add_argument('--tile', default=''); ap.add_argument('--c', type=int, default=48)
 args = ap.parse_args()
 csrc = os.path.join(ROOT, 'part-aware_measurement_for_3d_pose_estimation_and_tracking_amd', 'csrc')
 so = '/tmp/libbb2_diag_%d.so' % os.getpid()
@@ -16,7 +16,8 @@ from pam import _lib, hrnet_hip
 lib = C.CDLL(so)
 lib.pam_basic_block2_nhwc_bf16.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6
 dev = torch.device('cuda:0')
-c, h, w = 48, 96, 72
+c = args.c
+h, w = {48: (96, 72), 96: (48, 36)}[c]
 op = hrnet_hip.PackedBlock(nn.Conv2d(c, c, 3, 1, 1), nn.Conv2d(c, c, 3, 1, 1), dev)
 x = torch.randn((args.n, c, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
 y = torch.empty_like(x)
