@@ -418,7 +418,7 @@ def panoptic31_runs(torch, dist, synth, args, net, K, W, world, rank, local_rank
            'sharding': 'camera views partitioned over ranks, each rank holds its own cameras only',
            'views_per_rank': [len(p) for p in view_partition(meta['C'], world)], 'crops_per_rank': inp['parts'],
            'final_tracks': [t['track_id'] for t in fin['tracks'] if t['emitted']], 'tracker_status': fin['status'] | fin['status_sticky'],
-           'conv_executor': ({str(n): t['choice'] for n, t in net.tuned.items()} if net is not None and net.autotune else None)}
+           'conv_executor': ({str(n): t['choice'] for n, t in net.tuned.items()} if net is not None else None)}
     del pipe, inp
     if not args.no_extra:
         res.update(scaling_extras(torch, dist, synth, args, wl, net, 'views', K, W, world, rank, local_rank, dev, max_dets, res['value']))
@@ -502,10 +502,9 @@ def main():
     work = {}
     for n in sorted(set(local_crops[W:])):
         if n > 0:
-            cfgname = 'grouped'
-            if pipe.net is not None and pipe.net.backend == 'hip':
-                cfgname = pipe.net.tuned[n]['choice'] if (pipe.net.autotune and n in pipe.net.tuned) else pipe.net.hip.config_name
+            cfgname = pipe.net.config_for(n) if (pipe.net is not None and pipe.net.backend == 'hip') else None
             work[n] = hrnet_mod.algorithmic_work(n, config=cfgname)
+            work[n]['config'] = cfgname
     hr_ms = [a.elapsed_time(b) for (a, b), n in zip(evs, local_crops[W:]) if n > 0]
     hr_fl = [work[n]['flops'] for n in local_crops[W:] if n > 0]
     hr_by = [work[n]['bytes'] for n in local_crops[W:] if n > 0]
@@ -540,18 +539,20 @@ def main():
                        'tracker': 'fused HIP frame kernel (f64), replicated after the exchange',
                        'tracker_stream_on_its_own_hw_queue': bool(pipe.track_overlaps) if overlap else None, 'hrnet_weights': pipe.net.weights if pipe.net else None,
                        'conv_backend': pipe.net.backend if pipe.net else None,
-                       'conv_executor': ({str(n): t for n, t in pipe.net.tuned.items()} if pipe.net is not None and pipe.net.autotune else
-                                         (pipe.net.hip.config_name if pipe.net is not None and pipe.net.backend == 'hip' else None)),
+                       'conv_executor': ({str(n): t for n, t in pipe.net.tuned.items()} if pipe.net is not None and pipe.net.backend == 'hip' else None),
                        'exchange': ('one all-gather per frame (%s)' % ('pam_allgather_keypoints: RCCL called inside the C ABI' if pipe.comm else 'torch.distributed ' + backend)) if world > 1 else 'none',
                        'devices': '%d ranks on ONE device (no multi-GPU box: functional check only)' % world if single_dev and world > 1 else '%d' % world},
-            'roofline': {'kernel': 'HRNet-W48 conv stack: k_bblock / k_conv3x3[s] / k_conv_gs / k_conv_igemm / k_pw1 / k_pw2 / k_upsample_add (hipGraph replay, %d crops, %d launches)'
-                                   % (n_med, launches),
-                         'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': avg_ms,
-                         'algorithmic_bytes': work[n_med]['bytes'] if n_med in work else None,
-                         'note': 'group-level view: 220 FLOP/B < the 312 FLOP/B ridge; the per-family bounds (hbm / mfma / latency) are in families[]',
-                         'mfma': {'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                  'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'flops': work[n_med]['flops'] if n_med in work else None}},
+            'roofline': {'kernel': 'HRNet-W48 conv stack: k_bblock2_48 / k_bblock2_96 / k_conv3x3[s] / k_conv_gs / k_conv_igemm / k_pw1 / k_pw2 / k_upsample_add '
+                                   '(hipGraph replay, %d crops, %d launches, executor configuration %s)' % (n_med, launches, work[n_med]['config'] if n_med in work else None),
+                         # this group is a dense contraction -> priced against the bf16 MFMA peak (algorithmic FLOPs / replay time)
+                         'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / MFMA_BF16_PEAK_TFLOPS, 'flops': work[n_med]['flops'] if n_med in work else None,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'avg_launch_ms': avg_ms,
+                         'note': 'per-family bounds (hbm / mfma / latency) are in families[]; hbm = the secondary view of the same replay',
+                         # executor-independent bytes of the module graph (block interiors uncounted): un-fusing cannot raise this fraction
+                         'hbm': {'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved_gbs / HBM_PEAK_GBS,
+                                 'algorithmic_bytes': work[n_med]['bytes'] if n_med in work else None,
+                                 'bytes_as_executed': work[n_med]['bytes_as_executed'] if n_med in work else None}},
             'final_tracks': [t['track_id'] for t in final['tracks'] if t['emitted']], 'tracker_status': final['status'] | final['status_sticky'],
         }
 
@@ -609,7 +610,10 @@ def main():
         out['kernels'] = kern
         if not args.no_families and n > 0 and pipe.net is not None and pipe.net.backend == 'hip':
             fam = conv_families(torch, pipe.net, n, avg_ms)
+            # the families describe the executor that was timed: same configuration, same number of launches as the replay
+            assert n != n_med or fam['launches'] == launches == sum(f['launches'] for f in fam['families']), (fam['launches'], launches)
             out['roofline']['families'] = fam['families']
+            out['roofline']['families_config'] = fam['config']
             out['roofline']['families_note'] = fam['note']
         if not args.no_surface and world == 1:
             out['surface'] = surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, min(K, 60), min(W, 5))
@@ -654,6 +658,7 @@ def conv_families(torch, net, n, stack_ms):
     x = net.input_buffer(n)
     saved = (hip.multi_stream, hip.prof)
     hip.multi_stream = False
+    hip.apply_config(net.config_for(n))                   # the configuration the replay of n crops was captured in
     try:
         with torch.no_grad():
             hip.prof = []
@@ -688,7 +693,7 @@ def conv_families(torch, net, n, stack_ms):
                      'hbm_frac': fh, 'mfma_frac': fm, 'achieved_GBs': gbs, 'achieved_TFLOPs': tfs})
     fams.sort(key=lambda f: -f['us_total'])
     serial = sum(f['us_total'] for f in fams) * 1e-3
-    return {'families': fams, 'note': 'each distinct launch alone on the chip (20 back-to-back repetitions between HIP events); sum over the '
+    return {'families': fams, 'launches': len(rec), 'config': hip.config_name, 'note': 'each distinct launch alone on the chip (20 back-to-back repetitions between HIP events); sum over the '
                                       'forward %.3f ms vs %.3f ms for the multi-stream hipGraph replay of the same forward' % (serial, stack_ms)}
 
 
@@ -822,24 +827,30 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
             quota = float(q[0]) / float(q[1])
     except Exception:
         pass
+    usable = avail if quota is None else max(1, min(avail, int(quota + 0.5)))     # cores this process can actually run on
     best = None
     limit_s = 25.0
     code = ("import sys, time, torch; sys.path.insert(0, %r); import pam; from pam import hrnet as H; torch.set_num_threads(%d); "
             "m = H.fold_batchnorm(H.init_random(H.PoseHighResolutionNet())).eval(); x = torch.randn(%d, 3, 384, 288)\n"
             "with torch.no_grad():\n    m(x[:1]); t0 = time.perf_counter(); m(x); print('BATCH_S', time.perf_counter() - t0)" % (ROOT, avail, crops))
-    try:
-        pr = subprocess.run([sys.executable, '-c', code], timeout=limit_s, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-        got = [l for l in pr.stdout.splitlines() if l.startswith('BATCH_S')]
-        if got:
-            t_all = float(got[-1].split()[1])
-            runs.append({'threads': avail, 's_per_batch': t_all, 'timed_forwards': 1, 'where': 'child process'})
-            best = (t_all, avail)
-        else:
-            runs.append({'threads': avail, 's_per_batch': None, 'skipped': 'child process failed (rc %d)' % pr.returncode})
-    except subprocess.TimeoutExpired:
-        runs.append({'threads': avail, 's_per_batch': None, 'skipped': 'not finished within %.0f s (oversubscribed team)' % limit_s})
+    if usable < avail:
+        # the cgroup gives this process fewer cores than it can see: a team of `avail` threads is oversubscribed by construction (round 3
+        # burned 25 s of every run on a 256-thread attempt that timed out on a 16-core quota) -- not attempted
+        runs.append({'threads': avail, 's_per_batch': None, 'skipped': 'cgroup quota is %.1f cores of %d visible' % (quota, avail)})
+    else:
+        try:
+            pr = subprocess.run([sys.executable, '-c', code], timeout=limit_s, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            got = [l for l in pr.stdout.splitlines() if l.startswith('BATCH_S')]
+            if got:
+                t_all = float(got[-1].split()[1])
+                runs.append({'threads': avail, 's_per_batch': t_all, 'timed_forwards': 1, 'where': 'child process'})
+                best = (t_all, avail)
+            else:
+                runs.append({'threads': avail, 's_per_batch': None, 'skipped': 'child process failed (rc %d)' % pr.returncode})
+        except subprocess.TimeoutExpired:
+            runs.append({'threads': avail, 's_per_batch': None, 'skipped': 'not finished within %.0f s (oversubscribed team)' % limit_s})
     with torch.no_grad():
-        for thr in [c for c in (16, 32, 64) if c < avail] or [avail]:
+        for thr in sorted(set([usable] + [c for c in (16, 32, 64) if c < usable])) if usable < avail else ([c for c in (16, 32, 64) if c < avail] or [avail]):
             if any(r['threads'] == thr and r.get('s_per_batch') for r in runs):
                 continue
             t_thr, reps = batch_time(thr, 6.0)
@@ -848,7 +859,7 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
                 best = (t_thr, thr)
     probe = {'cgroup_cpu_quota_cores': quota}
     t_hr, thr = best
-    return {'value': 1.0 / (t_hr + t_match), 'unit': 'frames/s', 'cores': avail, 'cpu_count': ncpu, 'affinity_cores': avail,
+    return {'value': 1.0 / (t_hr + t_match), 'unit': 'frames/s', 'cores': usable, 'cpu_count': ncpu, 'affinity_cores': avail,
             'threads': thr, 'kind': 'port',
             'sample': 'oracle tracker (1 thread) over %d frames: %.2f ms/frame; HRNet-W48 fp32 CPU PyTorch, real batches of %d crops (one frame): '
                       '%s; baseline = the fastest (%d threads, %.3f s/frame)'

@@ -244,38 +244,17 @@ int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int n_terms, c
                                   const int32_t* term_cstrides, void* out, int N, int H, int W, int C, int relu);
 
 /* ---- fused HRNet BasicBlock (row a1; stands inside the absent HRNet backend behind /root/reference/src/ivclabpose.py:210).
- * out = ReLU(conv3x3(ReLU(conv3x3(in) + b1)) + b2 + in), NHWC bf16, C -> C -> C, stride 1, pad 1, BatchNorm folded; the
- * intermediate never leaves LDS.  One launch runs the blocks of up to PAM_BLOCK_MAX_BRANCHES independent tensors (the
- * branches of one HR module).  Supported C: 48, 96, 192 with W + 2 <= 76 / 40 / 24; pam_basic_block_rows returns the rows per
- * work item for a workgroup shape (waves = 4 / 8, 0 = any; result 0 = not supported: use two pam_conv2d_nhwc_bf16 calls).
- * w_img: 2 * NCH chunk images of CHB bytes (conv1's chunks, then conv2's); a chunk is KS consecutive k-step sub-images
- * [C rows][PWT = 64 bytes = 4 pieces of 8 bf16]; k-step = 32 K elements, K = flattened (tap, cin) index padded with zeros to
- * NSTEP*32; row R = output channel 48*(R/48) + 12*((R%16) >> 2) + 4*((R%48)/16) + (R & 3), and physical piece p of row R holds
- * K elements 8*(p ^ s) .. +7 of the k-step with s = (0,2,3,1)[(R%16) >> 2] (LDS bank swizzle).
- * pam_basic_block_chunk_layout writes {KS, NCH, PWT, CHB, NSTEP}.
- * bias: float32 [2][C] (conv1, conv2).  in != out. */
-#define PAM_BLOCK_MAX_BRANCHES 4
-typedef struct PamBlockDesc {
-    const void* in; const void* w_img; const float* bias; void* out;
-    int32_t N, H, W, C;
-} PamBlockDesc;
-int pam_basic_block_rows(int C, int H, int W, int waves);
-int pam_basic_block_chunk_layout(int C, int32_t* out5);
-int pam_basic_block_nhwc_bf16(void* stream, int n_branches, const PamBlockDesc* blocks);
-/* waves: 4 = 256-thread workgroups, two per CU (C = 48 / 96 only), 8 = 512-thread workgroups, 0 = 4 when every branch allows it;
- * with 8, bits 4-7 are a mask: bit k set = branch k of the call runs as "short" items (4-row tiles with their own M-tile counts: twice
- * the items at about half the cost each, C = 48 / 96) -- a packing choice for grouped launches, same results */
-int pam_basic_block_nhwc_bf16_ex(void* stream, int n_branches, const PamBlockDesc* blocks, int waves);
-
-/* ---- the same BasicBlock as ONE launch per tensor with 2-D items of tile_rows x tile_cols output positions (csrc/pam_block2.hip), all
+ * out = ReLU(conv3x3(ReLU(conv3x3(in) + b1)) + b2 + in), NHWC bf16, C -> C -> C, stride 1, pad 1, BatchNorm folded; the intermediate
+ * never leaves LDS.  ONE launch per tensor with 2-D items of tile_rows x tile_cols output positions (csrc/pam_block2.hip), all
  * operands fetched by LDS-DMA.  pam_basic_block2_tile writes the {rows, cols} the library would pick for N x H x W (whole rounds of 256
  * workgroups first, then the least work per item); tile_rows / tile_cols <= 0 in the launch = that choice.  in != out.
  * C = 48 (k_bblock2_48): BOTH weight sets resident in LDS beside a 75 KB input tile, no barrier inside the K loops.  Limits:
  *   (rows + 4)(cols + 4) <= 800, (rows + 2)(cols + 4) <= 768, rows (cols + 2) <= 640.
  *   wpack (1 024 + 86 016 bytes): [float32 bias: conv1's 48, conv2's 48, zero padding to 1 KiB][conv1's 14 k-step images][conv2's 14]; a
- *   k-step image = [48 rows][64 bytes] as pam_basic_block_nhwc_bf16's w_img for C = 48 except for the row -> channel rule: row
- *   j*16 + q = output channel 8*(q >> 2) + 4*j + (q & 3) for j < 2 and 32 + 4*(q >> 2) + (q & 3) for j = 2.  Results are
- *   bit-identical to pam_basic_block_nhwc_bf16's and to two pam_conv2d_nhwc_bf16 calls (same K order per output element).
+ *   k-step = 32 K elements, K = flattened (tap, cin) index padded with zeros to 14*32; a k-step image = [48 rows][64 bytes = 4 pieces
+ *   of 8 bf16]: row j*16 + q = output channel 8*(q >> 2) + 4*j + (q & 3) for j < 2 and 32 + 4*(q >> 2) + (q & 3) for j = 2, and
+ *   physical piece p of row R holds K elements 8*(p ^ s) .. + 7 of the k-step with s = (0,2,3,1)[(R%16) >> 2] (LDS bank swizzle).
+ *   Results are bit-identical to two pam_conv2d_nhwc_bf16 calls (same K order per output element).
  * C = 96 (k_bblock2_96<3,2> / <5,4>): the input tile resident (chunk-major, 3 x 32 channels), the weights of both convolutions
  *   streamed through a ring of six k-step images.  Limits: (rows + 4)(cols + 4) <= 640, (rows + 2)(cols + 4) <= 640, rows (cols + 2)
  *   <= 512 (half of the latter two for the small instantiation, which the picker prefers while it fills the chip).
@@ -306,29 +285,6 @@ int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const void* x0, 
                                   const float* bias3, const void* w1_img, const float* bias1, void* out_x, void* out_y1,
                                   long long n_pixels, int tile_cfg);
 
-/* ---- launch plans: the conv stack's forward as a recorded DAG of launches, replayed from C (csrc/pam_plan.hip) -------------------
- * Between pam_plan_begin() and pam_plan_end() the calling thread's convolution entry points (pam_conv2d_*, pam_basic_block_*,
- * pam_upsample_add_*, pam_bottleneck_tail_*) RECORD their kernel launches instead of issuing them: function, geometry and a copy of the
- * argument struct (device pointers baked in: the caller keeps those buffers alive and in place), on the logical stream chosen by
- * pam_plan_stream (0 = the stream given to pam_plan_replay, 1..7 = side streams the plan owns).  pam_plan_record marks the current
- * position of the current logical stream and returns an event id (>= 0); pam_plan_wait makes the current logical stream wait for such
- * an event -- the dependency-precise schedule of pam/hrnet_hip.py (a consumer waits for exactly the tensors it reads).
- * pam_plan_replay(plan, stream, mode): mode 0 issues the plan on real streams with real events in recorded order (side streams forked
- * from `stream` at the start and joined into it at the end); mode 1 builds one explicit hipGraph from the plan (hipGraphAddKernelNode
- * with the recorded dependencies) on first use and launches it.  Replaces the hipGraph capture of the forward: capturing streams that
- * wait on each other's events in both directions segfaults in hipStreamEndCapture on ROCm 7.2.  pam_plan_info: {launches, events,
- * logical streams, operations}. */
-int pam_plan_begin(void);
-int pam_plan_stream(int logical_stream);
-int pam_plan_record(void);
-int pam_plan_wait(int event_id);
-int pam_plan_end(void** plan);
-int pam_plan_abort(void);
-int pam_plan_info(const void* plan, int32_t* out4);
-int pam_plan_replay(void* plan, void* stream, int mode);
-int pam_plan_destroy(void* plan);
-const char* pam_plan_last_error(const void* plan);
-
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before
  * the cross-view match every rank contributes its views' keypoint records and receives everyone's: ONE all-gather per frame, enqueued on
@@ -343,22 +299,6 @@ int pam_comm_init(void** comm, int world, int rank, const void* id128, int devic
 int pam_comm_destroy(void* comm);
 const char* pam_comm_last_error(void);
 int pam_allgather_keypoints(PamHandle* h, void* comm, void* stream, const double* dev_send, int rows_per_rank, double* dev_recv);
-
-/* ---- grouped launches for the HRNet fuse layers (row a1): several small independent convolutions / several fuse sums in ONE
- * launch each -- a fuse layer is ~10 kernels of 10-40 us whose launch chain, not their arithmetic, is what takes time.
- * pam_conv2d_group_nhwc_bf16: up to 8 convolutions with the arguments of pam_conv2d_nhwc_bf16_ex (Cout % 48 == 0, relu 0 / 1);
- * pam_upsample_add_group_nhwc_bf16: up to 4 sums with the arguments of pam_upsample_add_nhwc_bf16_ex.  Outputs must not alias
- * inputs of other members of the same group. */
-typedef struct PamConvDesc {
-    const void* in; const void* w_packed; const float* bias; const void* residual; void* out;
-    int32_t N, H, W, Cin, Cout, KH, KW, stride, pad, relu, in_cstride, relu_from;
-} PamConvDesc;
-int pam_conv2d_group_nhwc_bf16(void* stream, int n, const PamConvDesc* convs);
-typedef struct PamUpDesc {
-    const void* base; const void* terms[3]; void* out;
-    int32_t shifts[3]; int32_t term_cstrides[3]; int32_t n_terms, N, H, W, C, relu;
-} PamUpDesc;
-int pam_upsample_add_group_nhwc_bf16(void* stream, int n, const PamUpDesc* sums);
 
 /* ---- person detector side (ivclabpose.py:116-120 constructs backend.YOLOv3, :183-204 PersonDetect calls it).
  * The backend is absent from the reference tree; these follow the public Darknet YOLOv3 definition (parity unpinned).

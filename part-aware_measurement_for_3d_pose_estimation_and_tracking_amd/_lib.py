@@ -28,28 +28,6 @@ class PamParams(C.Structure):
     ]
 
 
-class PamBlockDesc(C.Structure):
-    _fields_ = [('in_', C.c_void_p), ('w_img', C.c_void_p), ('bias', C.c_void_p), ('out', C.c_void_p),
-                ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('C', C.c_int32)]
-
-
-PAM_BLOCK_MAX_BRANCHES = 4
-
-
-class PamConvDesc(C.Structure):
-    _fields_ = [('in_', C.c_void_p), ('w_packed', C.c_void_p), ('bias', C.c_void_p), ('residual', C.c_void_p), ('out', C.c_void_p)] + \
-               [(n, C.c_int32) for n in ('N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride', 'pad', 'relu', 'in_cstride', 'relu_from')]
-
-
-class PamUpDesc(C.Structure):
-    _fields_ = [('base', C.c_void_p), ('terms', C.c_void_p * 3), ('out', C.c_void_p), ('shifts', C.c_int32 * 3),
-                ('term_cstrides', C.c_int32 * 3)] + [(n, C.c_int32) for n in ('n_terms', 'N', 'H', 'W', 'C', 'relu')]
-
-
-PAM_CONV_GROUP_MAX = 8
-PAM_UP_GROUP_MAX = 4
-
-
 class PamOutLayout(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'n_views', 'max_dets', 'max_tracks', 'n_scenes', 'int_words', 'dbl_words', 'hdr_words', 'trk_words',
@@ -95,31 +73,15 @@ _SIGS = {
     'pam_conv_debug_stamps': (_I, [_P]),
     'pam_upsample_add_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
     'pam_upsample_add_nhwc_bf16_ex': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
-    'pam_basic_block_rows': (_I, [_I, _I, _I, _I]),
-    'pam_basic_block_chunk_layout': (_I, [_I, _P]),
-    'pam_basic_block_nhwc_bf16': (_I, [_P, _I, _P]),
-    'pam_basic_block_nhwc_bf16_ex': (_I, [_P, _I, _P, _I]),
     'pam_basic_block2_tile': (_I, [_I, _I, _I, _I, _P]),
     'pam_basic_block2_nhwc_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     'pam_pointwise64_relu_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, C.c_longlong]),
     'pam_bottleneck_tail_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I]),
-    'pam_plan_begin': (_I, []),
-    'pam_plan_stream': (_I, [_I]),
-    'pam_plan_record': (_I, []),
-    'pam_plan_wait': (_I, [_I]),
-    'pam_plan_end': (_I, [C.POINTER(_P)]),
-    'pam_plan_abort': (_I, []),
-    'pam_plan_info': (_I, [_P, _P]),
-    'pam_plan_replay': (_I, [_P, _P, _I]),
-    'pam_plan_destroy': (_I, [_P]),
-    'pam_plan_last_error': (C.c_char_p, [_P]),
     'pam_comm_unique_id': (_I, [_P]),
     'pam_comm_init': (_I, [C.POINTER(_P), _I, _I, _P, _I]),
     'pam_comm_destroy': (_I, [_P]),
     'pam_comm_last_error': (C.c_char_p, []),
     'pam_allgather_keypoints': (_I, [_P, _P, _P, _P, _I, _P]),
-    'pam_conv2d_group_nhwc_bf16': (_I, [_P, _I, _P]),
-    'pam_upsample_add_group_nhwc_bf16': (_I, [_P, _I, _P]),
     'pam_head_decode_scratch_bytes': (C.c_longlong, [_I, _I, _I]),
     'pam_head_decode': (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     'pam_head_decode_soft_scratch_bytes': (C.c_longlong, [_I, _I, _I]),
@@ -164,14 +126,13 @@ def new_graph():
     """A torch.cuda.CUDAGraph that is NOT destroyed while the interpreter shuts down (every graph the package captures is one).
 
     Destroying a captured multi-stream graph on ROCm 7.2 corrupts the runtime's heap now and then (tools/graph_destroy_stress.py: 3 of
-    4 processes that tune 40 crop counts and destroy the 120 slower captures die of 'double free or corruption' / SIGSEGV inside a
-    LATER synchronize or allocation, 0 of 5 when nothing is destroyed; 2 of ~35 bench.py runs aborted the same way while the replay
-    tuner still dropped its slower captures at once).  So (i) the tuner keeps every capture for as long as its network lives
-    (HRNetPose._kept) -- a long-running process never destroys a graph -- and (ii) at interpreter exit every graph still alive gets
-    one reference that is never returned, so torch's destructor (hipGraphExecDestroy / hipGraphDestroy) does not run in the
-    teardown either and a finished run cannot turn into a non-zero exit code.  Graphs do die with their network when a process
-    drops one mid-run (the test-suite does); making them immortal outright was tried and is worse: with every capture of every
-    earlier network still alive, a replay in tests/test_gpu_image.py segfaults inside hipGraphLaunch (3 of 3 full-suite runs)."""
+    4 processes that capture 160 forwards and destroy 120 of them die of 'double free or corruption' / SIGSEGV inside a LATER
+    synchronize or allocation, 0 of 5 when nothing is destroyed).  The package therefore never drops a capture while its network lives
+    (one capture per crop-count bucket and replay slot, all of a slot in ONE memory pool), and at interpreter exit every graph still
+    alive gets one reference that is never returned, so torch's destructor (hipGraphExecDestroy / hipGraphDestroy) does not run in the
+    teardown either and a finished run cannot turn into a non-zero exit code.  Graphs do die with their network when a process drops one
+    mid-run (the test-suite does); making them immortal outright was tried and is worse: with every capture of every earlier network
+    still alive, a replay in tests/test_gpu_image.py segfaults inside hipGraphLaunch (3 of 3 full-suite runs)."""
     global _live_graphs
     import torch
     if _live_graphs is None:

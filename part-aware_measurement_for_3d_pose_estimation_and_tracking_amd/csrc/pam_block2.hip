@@ -630,14 +630,7 @@ static int launch_bb96(void* stream, const void* in, const void* wpack, void* ou
     const size_t reach = (size_t)2 * a.xsp * 64 + (size_t)(16 * B96_NW * kB96Inst[inst][0] + 2 * (a.TC + 4) + 3) * 64;
     if (reach > lds) lds = reach;
     if (lds > 160 * 1024) return PAM_E_ARG;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return PAM_E_HIP;
-    static unsigned long long attr_set = 0;
-    if (dev < 64 && !((attr_set >> dev) & 1)) {
-        if (hipFuncSetAttribute((const void*)k_bblock2_96<5, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_bblock2_96<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PAM_E_HIP;
-        attr_set |= 1ull << dev;
-    }
+    if (!pam_max_dynamic_lds((const void*)k_bblock2_96<5, 4>, 160 * 1024) || !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2>, 160 * 1024)) return PAM_E_HIP;
 #ifdef PAM_DIAG
     a.stamps = g_bb2_stamps;
 #endif
@@ -661,13 +654,7 @@ extern "C" int pam_basic_block2_nhwc_bf16(void* stream, const void* in, const vo
     a.inv_pwx = 1.0f / (float)(a.TC + 4); a.inv_pwi = 1.0f / (float)(a.TC + 2);
     a.xbytes = ((a.TR + 4) * (a.TC + 4) * PA + 1023) / 1024 * 1024;
     const size_t lds = (size_t)a.xbytes + (size_t)WPIECES * 1024;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return PAM_E_HIP;
-    static unsigned long long attr_set = 0;              // per device: the attribute belongs to the device's copy of the function
-    if (dev < 64 && !((attr_set >> dev) & 1)) {
-        if (hipFuncSetAttribute((const void*)k_bblock2_48, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return PAM_E_HIP;
-        attr_set |= 1ull << dev;
-    }
+    if (!pam_max_dynamic_lds((const void*)k_bblock2_48, 160 * 1024)) return PAM_E_HIP;
 #ifdef PAM_DIAG
     a.stamps = g_bb2_stamps;
 #endif

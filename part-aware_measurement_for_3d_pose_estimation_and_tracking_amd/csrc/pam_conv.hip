@@ -284,24 +284,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_igemm(ConvArgs a) {
     conv_igemm_body<NTW, WM, WN, GEN>(a, blockIdx.x, blockIdx.y);
 }
 
-// Several independent small convolutions in ONE launch (the convolutions of one level of an HRNet fuse layer: 1x1 up-convolutions
-// and strided 3x3 chains from every branch).  Workgroup b belongs to convolution g with first[g] <= b < first[g + 1]; inside it the
-// N tile varies fastest.  All use the 64-pixel x 48-channel single-wave tile: these layers are a few hundred such tiles each.
-#define PAM_CONV_GROUP_MAX 8
-struct ConvGroupArgs { ConvArgs c[PAM_CONV_GROUP_MAX]; int first[PAM_CONV_GROUP_MAX + 1]; int n; };
-__global__ __launch_bounds__(64) void k_conv_igemm_group(ConvGroupArgs g) {
-    const int b = blockIdx.x;
-    int k = 0;
-#pragma unroll
-    for (int q = 1; q < PAM_CONV_GROUP_MAX; ++q) if (q < g.n && b >= g.first[q]) k = q;
-    ConvArgs a = g.c[0];
-    int f0 = g.first[0];
-#pragma unroll
-    for (int q = 1; q < PAM_CONV_GROUP_MAX; ++q) if (k == q) { a = g.c[q]; f0 = g.first[q]; }
-    const int nb = a.Cout / 48, l = b - f0;
-    conv_igemm_body<3, 1, 1, false>(a, l / nb, l - (l / nb) * nb);
-}
-
 template <int NTW, int WM, int WN>
 static int launch_conv(hipStream_t s, const ConvArgs& a) {
     constexpr int BM_ = 64 * WM, BN_ = 16 * NTW * WN;
@@ -919,27 +901,19 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
 // (LDS ring): the tile is the tallest whole-row tile that fits (a divisor of H when that costs < 15 %).
 // Cin 96 stays on k_conv3x3: its streamed form (96-channel slabs, 160 workgroups) is as fast alone (12.9 vs 13.0 us) but 3-5 % slower
 // end to end -- a 150 KB workgroup shuts the other branches out of its CU, and the 48 x 36 layers have enough tiles to fill the chip.
-// c96_slab: 0 = 96 -> 96 layers stay on k_conv3x3; 48 / 96 = they run here with slabs of that many output channels (the caller states it per
-// launch: tile_cfg -5 / -6 of pam_conv2d_nhwc_bf16_ex, and packs the weight image for that slab: pam_conv3x3_layout_ex)
+// c96_slab: 0 = 96 -> 96 layers stay on k_conv3x3; 48 = they run here with 48-channel slabs and a two-slot ring (the caller states it per
+// launch: tile_cfg -5 of pam_conv2d_nhwc_bf16_ex, and packs the weight image for that slab: pam_conv3x3_layout_ex)
 static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax, int& ntw, int c96_slab = 0) {
     // layer1 / transition1 of HRNet (64 -> 64 and 256 -> 48 at 96 x 72: ReLU layers; the detector's 64- and 256-channel 3x3 layers have
     // other widths and a leaky activation and stay on k_conv3x3): two rounds of 480 workgroups, still 24 -> 16 us and 59 -> 30 us
     const bool l1 = (Cin == 64 && Cout == 64) || (Cin == 256 && Cout == 48);
-    const bool c96 = Cin == 96 && Cout == 96 && (c96_slab == 48 || c96_slab == 96);
+    const bool c96 = Cin == 96 && Cout == 96 && c96_slab == 48;
     if (Cin != 192 && Cin != 384 && !l1 && !c96) return false;
 #ifdef PAM_DIAG
     static const int mask = getenv("PAM_C3S_MASK") ? atoi(getenv("PAM_C3S_MASK")) : 14;      // tuning hook: 2 = Cin 192, 4 = 384, 8 = 64 / 256
     if (!(mask & (Cin == 192 ? 2 : (Cin == 384 ? 4 : 8)))) return false;
 #endif
-    // 8 M tiles per wave / 576 patch slots = a whole 24 x 18 image per workgroup (half the workgroups, weights streamed once per image):
-    // measured 24.3 vs 11.2 us per convolution (256 VGPRs, 31 spilled) and 3.03-3.07 vs 2.65-2.68 ms per 20-crop forward -- the 192-channel
-    // chain becomes the module's critical path.  Off; -DPAM_C3S_TALL builds it (tools/ab_build.sh).
-#ifdef PAM_C3S_TALL
-    const bool tall = Cin == 192;
-#else
-    const bool tall = false;
-#endif
-    const int PW = W + 2, smax = tall ? 512 : 320, pcap = l1 ? 448 : (tall ? 576 : 384);
+    const int PW = W + 2, smax = 320, pcap = l1 ? 448 : 384;
     // rows per tile: the height that costs the fewest M tiles over the image (a tile always multiplies whole 64-slot wave shares, 3 to
     // 5 of them, and a ragged last tile multiplies as much as a full one); ties go to the taller tile = fewer workgroups
     TH = 0; mt = 0; pmax = 0;
@@ -948,11 +922,10 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
         const int sl = t * PW, np = (t + 2) * PW;
         if (np > pcap) continue;
         // the instantiated (M tiles per wave, patch slots) shapes: (3, 192), (4, 320), (5, 384 | 448) -- the smallest that holds the tile
-        const int m = (sl <= 192 && np <= 192) ? 3 : ((sl <= 256 && np <= 320) ? 4 : ((sl <= 320 && np <= 448) ? 5 : 8));
-        if (m == 8 && !tall) continue;
-        if (m == 5 && c96 && c96_slab == 96) continue;         // 5 x 6 accumulator tiles per wave do not fit 256 registers
+        if (sl > 320 || np > 448) continue;
+        const int m = (sl <= 192 && np <= 192) ? 3 : ((sl <= 256 && np <= 320) ? 4 : 5);
         const long cost = (long)((H + t - 1) / t) * m;
-        if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : (m == 8 ? 576 : (np <= 384 ? 384 : 448))); }
+        if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 3 ? 192 : (m == 4 ? 320 : (np <= 384 ? 384 : 448)); }
     }
     if (TH < 1) return false;
     const int bn = c96 ? c96_slab : (Cout == 48 ? 48 : 64);
@@ -973,11 +946,7 @@ template <int CIN, int NTW, int MT, int PMAX, int NBUF>
 static int launch_c3s_one(hipStream_t s, const C3Args& a) {
     constexpr size_t lds = (size_t)NBUF * (PMAX * 64 + 9 * 16 * NTW * 64);
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
-        attr = true;
-    }
+    if (!pam_max_dynamic_lds((const void*)k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>, (int)lds)) return PAM_E_HIP;
     pam_launch(k_conv3x3s<CIN, NTW, MT, PMAX, NBUF>, dim3(a.tiles_y * a.N, a.Cout / (16 * NTW)), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
@@ -1004,9 +973,6 @@ static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, 
         case 9633: return launch_c3s_one<96, 3, 3, 192, 2>(s, a);
         case 9634: return launch_c3s_one<96, 3, 4, 320, 2>(s, a);
         case 9635: return launch_c3s_one<96, 3, 5, 384, 2>(s, a);
-        case 9663: return launch_c3s_one<96, 6, 3, 192, 2>(s, a);      // all 96 output channels per workgroup: the patch is fetched once
-        case 9664: return launch_c3s_one<96, 6, 4, 320, 2>(s, a);
-        case 19248: return launch_c3s_one<192, 4, 8, 576, 2>(s, a);
         case 19243: return launch_c3s_one<192, 4, 3, 192, 3>(s, a);
         case 19244: return launch_c3s_one<192, 4, 4, 320, 2>(s, a);
         case 19245: return launch_c3s_one<192, 4, 5, 384, 2>(s, a);
@@ -1235,11 +1201,7 @@ template <int NTW, bool RES, int BM = 256, int NBUF = 3>
 static int launch_conv_gs_r(hipStream_t s, const ConvArgs& a) {
     constexpr size_t lds = (size_t)NBUF * (BM + 16 * NTW) * 128;
     static_assert(lds <= 160 * 1024, "LDS");
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_conv_gs<NTW, NBUF, RES, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
-        attr = true;
-    }
+    if (!pam_max_dynamic_lds((const void*)k_conv_gs<NTW, NBUF, RES, BM>, (int)lds)) return PAM_E_HIP;
     const int ntile = ((a.M + BM - 1) / BM) * (a.Cout / (16 * NTW));
     pam_launch(k_conv_gs<NTW, NBUF, RES, BM>, dim3(ntile < 256 ? ntile : 256), dim3(512), lds, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
@@ -1341,8 +1303,8 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     // tile_cfg -3 / -4: automatic like -1, but the caller STATES the layout of w_img (streamed / classic) instead of leaving it to
     // pam_conv3x3_layout() at call time -- a launch recorded under one setting of pam_conv_option and re-issued under another must not
     // read an image in the other layout
-    // -5 / -6: streamed, and a 96 -> 96 layer's image is packed for slabs of 48 / 96 output channels
-    const int c96_slab = tile_cfg == -5 ? 48 : (tile_cfg == -6 ? 96 : 0);
+    // -5: streamed, and a 96 -> 96 layer's image is packed for slabs of 48 output channels
+    const int c96_slab = tile_cfg == -5 ? 48 : 0;
     const bool force_streamed = tile_cfg == -3 || c96_slab != 0, no_streamed = tile_cfg == -4;
     if (force_streamed || no_streamed) tile_cfg = -1;
     if (in_cstride != Cin || relu_from != 0) { if (force_streamed) return PAM_E_ARG; w_img = nullptr; }   // sliced input / partial activation: generic kernel only
@@ -1540,107 +1502,5 @@ extern "C" int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     pam_launch(k_upsample_add, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
-}
-
-extern "C" int pam_conv2d_group_nhwc_bf16(void* stream, int n, const PamConvDesc* d) {
-    if (n < 1 || n > PAM_CONV_GROUP_MAX || !d) return PAM_E_ARG;
-    ConvGroupArgs g;
-    g.n = n;
-    int blocks = 0;
-    for (int k = 0; k < n; ++k) {
-        const PamConvDesc& s = d[k];
-        const int in_cs = s.in_cstride > 0 ? s.in_cstride : s.Cin;
-        if (!s.in || !s.w_packed || !s.out || s.N <= 0 || s.H <= 0 || s.W <= 0 || s.Cin % 8 != 0 || s.Cout % 48 != 0 || s.KH < 1 || s.KW < 1 ||
-            s.KH > 3 || s.KW > 3 || s.stride < 1 || (s.relu != 0 && s.relu != 1) || in_cs < s.Cin || in_cs % 8 != 0 || s.relu_from < 0 ||
-            s.relu_from % 16 != 0 || s.H >= 32768 || s.W >= 32768)
-            return PAM_E_ARG;
-        ConvArgs& a = g.c[k];
-        a.in = (const uint16_t*)s.in; a.w = (const uint16_t*)s.w_packed; a.bias = s.bias; a.res = (const uint16_t*)s.residual; a.out = (uint16_t*)s.out;
-        a.N = s.N; a.H = s.H; a.W = s.W; a.Cin = s.Cin; a.Cout = s.Cout; a.KH = s.KH; a.KW = s.KW; a.stride = s.stride; a.pad = s.pad; a.relu = s.relu;
-        a.in_cs = in_cs; a.relu_from = s.relu_from;
-        a.Ho = (s.H + 2 * s.pad - s.KH) / s.stride + 1; a.Wo = (s.W + 2 * s.pad - s.KW) / s.stride + 1;
-        a.Ktot = s.KH * s.KW * s.Cin; a.Kpad = (a.Ktot + KC - 1) / KC * KC; a.M = s.N * a.Ho * a.Wo;
-        g.first[k] = blocks;
-        blocks += ((a.M + 63) / 64) * (s.Cout / 48);
-    }
-    for (int k = n; k < PAM_CONV_GROUP_MAX; ++k) { g.c[k] = g.c[0]; g.first[k] = blocks; }
-    g.first[PAM_CONV_GROUP_MAX] = blocks;
-    const size_t lds = 2 * (size_t)(64 + 48) * ROWB;          // members may differ in K: always both buffers
-    pam_launch(k_conv_igemm_group, dim3(blocks), dim3(64), lds, (hipStream_t)stream, g);
-    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
-}
-
-// the sums of ALL outputs of a fuse layer in one launch: workgroups [first[k], first[k + 1]) walk sum k
-#define PAM_UP_GROUP_MAX 4
-struct UpGroupArgs { UpArgs u[PAM_UP_GROUP_MAX]; int first[PAM_UP_GROUP_MAX + 1]; int n; };
-__device__ __forceinline__ void upsample_add_body(const UpArgs& a, unsigned b0, unsigned nblk) {
-    const unsigned C8 = (unsigned)a.C >> 3, total = (unsigned)a.N * a.H * a.W * C8;
-    for (unsigned e = b0 * 256 + threadIdx.x; e < total; e += nblk * 256) {
-        const unsigned pix = e / C8, c8 = e - pix * C8;
-        const unsigned t2 = pix / (unsigned)a.W, x = pix - t2 * a.W;
-        const unsigned n = t2 / (unsigned)a.H, y = t2 - n * a.H;
-        const bf16x8 b = *(const bf16x8*)(a.base + (size_t)pix * a.C + c8 * 8);
-        bf16x8 q[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            q[t] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (t < a.nterms) {
-                const unsigned hs = (unsigned)a.H >> a.sh[t], ws = (unsigned)a.W >> a.sh[t];
-                q[t] = *(const bf16x8*)(a.term[t] + ((size_t)(n * hs + (y >> a.sh[t])) * ws + (x >> a.sh[t])) * a.tcs[t] + c8 * 8);
-            }
-        }
-        float v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32((uint16_t)b[k]);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            if (t < a.nterms) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += bf16_to_f32((uint16_t)q[t][k]);
-            }
-        bf16x8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = (short)f32_to_bf16_rne(a.relu ? fmaxf(v[k], 0.0f) : v[k]);
-        *(bf16x8*)(a.out + (size_t)pix * a.C + c8 * 8) = o;
-    }
-}
-__global__ __launch_bounds__(256) void k_upsample_add_group(UpGroupArgs g) {
-    const int b = blockIdx.x;
-    int k = 0;
-#pragma unroll
-    for (int q = 1; q < PAM_UP_GROUP_MAX; ++q) if (q < g.n && b >= g.first[q]) k = q;
-    UpArgs a = g.u[0];
-    int f0 = g.first[0], f1 = g.first[1];
-#pragma unroll
-    for (int q = 1; q < PAM_UP_GROUP_MAX; ++q) if (k == q) { a = g.u[q]; f0 = g.first[q]; f1 = g.first[q + 1]; }
-    upsample_add_body(a, (unsigned)(b - f0), (unsigned)(f1 - f0));
-}
-
-extern "C" int pam_upsample_add_group_nhwc_bf16(void* stream, int n, const PamUpDesc* d) {
-    if (n < 1 || n > PAM_UP_GROUP_MAX || !d) return PAM_E_ARG;
-    UpGroupArgs g;
-    g.n = n;
-    int blocks = 0;
-    for (int k = 0; k < n; ++k) {
-        const PamUpDesc& s = d[k];
-        if (!s.base || !s.out || s.n_terms < 0 || s.n_terms > 3 || s.C % 8 != 0 || (size_t)s.N * s.H * s.W * (s.C / 8) >= (1ull << 31)) return PAM_E_ARG;
-        UpArgs& a = g.u[k];
-        a.base = (const uint16_t*)s.base; a.out = (uint16_t*)s.out; a.nterms = s.n_terms;
-        for (int t = 0; t < 3; ++t) {
-            a.term[t] = t < s.n_terms ? (const uint16_t*)s.terms[t] : nullptr; a.sh[t] = t < s.n_terms ? s.shifts[t] : 0;
-            a.tcs[t] = (t < s.n_terms && s.term_cstrides[t] > 0) ? s.term_cstrides[t] : s.C;
-            if (a.tcs[t] < s.C || a.tcs[t] % 8 != 0) return PAM_E_ARG;
-        }
-        a.N = s.N; a.H = s.H; a.W = s.W; a.C = s.C; a.relu = s.relu;
-        const size_t total = (size_t)s.N * s.H * s.W * (s.C / 8);
-        int nb = (int)((total + 255) / 256);
-        if (nb > 2048) nb = 2048;
-        g.first[k] = blocks;
-        blocks += nb;
-    }
-    for (int k = n; k < PAM_UP_GROUP_MAX; ++k) { g.u[k] = g.u[0]; g.first[k] = blocks; }
-    g.first[PAM_UP_GROUP_MAX] = blocks;
-    pam_launch(k_upsample_add_group, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

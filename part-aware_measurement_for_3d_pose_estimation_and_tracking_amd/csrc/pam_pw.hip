@@ -224,11 +224,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_pw2(PwArgs a) {
 template <int S, bool RES, bool HAS2, int MT, int NW>
 static int launch_pw2(hipStream_t s, const PwArgs& a, int max_wg) {
     constexpr size_t lds = (size_t)S * 32768 + (HAS2 ? 32768 : 0);
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)k_pw2<S, RES, HAS2, MT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return PAM_E_HIP;
-        attr = true;
-    }
+    if (!pam_max_dynamic_lds((const void*)k_pw2<S, RES, HAS2, MT, NW>, (int)lds)) return PAM_E_HIP;
     const int nwt = (a.M + 16 * MT - 1) / (16 * MT);
     int grid = (nwt + NW - 1) / NW;
     if (grid > max_wg) grid = max_wg;                   // persistent: one workgroup per CU, every wave walks wave tiles wt, wt + NW grid, ...

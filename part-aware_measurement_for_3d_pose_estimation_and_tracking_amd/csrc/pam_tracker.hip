@@ -192,7 +192,15 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
     int* out_i = A.out_i + (size_t)sidx * A.ol.int_words;
     double* out_d = A.out_d + (size_t)sidx * A.ol.dbl_words;
 #define DET(v, k) (det + (size_t)(vrow ? vrow[v] : (v)) * recd + (size_t)(k) * J3)
-#define NDET_RAW(v) (vrow ? (int)det[(size_t)vrow[v] * recd + (size_t)MAXP * J3] : n_det[v])
+    // view-sharded records carry the count as a double: a non-finite or out-of-range value is clamped explicitly (never cast: the
+    // conversion of a NaN is undefined) and raises ST_NDET_CLAMPED below
+    auto rec_count = [&](int v) -> double { return det[(size_t)vrow[v] * recd + (size_t)MAXP * J3]; };
+    auto count_of = [&](int v) -> int {
+        if (!vrow) return n_det[v];
+        const double c = rec_count(v);
+        return (c >= 0.0 && c <= (double)MAXP) ? (int)c : (c > (double)MAXP ? MAXP + 1 : -1);
+    };
+#define NDET_RAW(v) count_of(v)
     const int nT = st.hdr[0];
     // device-side counts are not validated by the host (pam_frame_dev): clamp them so that no index leaves det / ws.taken
 #define NDET(v) min(max(NDET_RAW(v), 0), MAXP)

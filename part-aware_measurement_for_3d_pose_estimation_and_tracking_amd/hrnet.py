@@ -182,17 +182,20 @@ def count_flops(c=48, num_joints=17, h=384, w=288):
     return total[0]
 
 
-def algorithmic_work(n_crops, resolution=(384, 288), config='grouped'):
-    """Unique HBM bytes and FLOPs of one conv-stack forward on the HIP backend (shape-only walk on the meta device) in the given
-    executor configuration (HipHRNet.CONFIGS): per convolution input + weights + bias [+ residual] + output, per fused block input +
-    both weight sets + output, per fuse sum base + terms + output."""
+def algorithmic_work(n_crops, resolution=(384, 288), config=None):
+    """Algorithmic work of one conv-stack forward (shape-only walks on the meta device):
+    ``bytes``: EXECUTOR-INDEPENDENT unique HBM bytes of the module graph -- every BasicBlock / Bottleneck counted as input + its weights and
+    biases + output (block interiors are not traffic the algorithm needs: a fused launch keeps them on chip), every other convolution as
+    input + weights + bias + output, every fuse-layer sum as base + terms + output.  Un-fusing a block cannot raise this number.
+    ``flops``; ``launches`` and ``bytes_as_executed`` (per launch: in + weights + bias [+ residual] + out) of the given executor
+    configuration (HipHRNet.CONFIGS; None = the default)."""
     from .hrnet_hip import HipHRNet
 
     from . import _lib as _real
 
     class _MetaLib(object):
         def __getattr__(self, name):
-            if name in ('pam_basic_block_rows', 'pam_conv3x3_slab', 'pam_conv3x3_layout'):       # pure host-side shape queries: the executor's plan depends on them
+            if name in ('pam_conv3x3_slab', 'pam_conv3x3_layout', 'pam_conv3x3_layout_ex'):       # pure host-side shape queries: the executor's plan depends on them
                 return getattr(_real.load(), name)
             return lambda *a, **k: 0
     eng = HipHRNet.__new__(HipHRNet)
@@ -200,11 +203,37 @@ def algorithmic_work(n_crops, resolution=(384, 288), config='grouped'):
     model = fold_batchnorm(PoseHighResolutionNet())
     model.final_layer = nn.Identity()
     HipHRNet._pack(eng, model, torch.device('meta'))
-    eng.apply_config(config)
+    eng.apply_config(config or HipHRNet.config_name)
     eng.count = dict(bytes=0, flops=0, launches=0)
     x = torch.empty((n_crops, 8, resolution[0], resolution[1]), dtype=torch.bfloat16, device='meta').contiguous(memory_format=torch.channels_last)
     eng._features(x)
-    return eng.count
+    # the module graph itself: hooks on the blocks (whole), on the convolutions outside blocks, and the fuse sums from the module's shapes
+    total = [0]
+    inside = set()
+    for m in model.modules():
+        if isinstance(m, (BasicBlock, Bottleneck)):
+            inside.update(id(c) for c in m.modules() if c is not m)
+    pbytes = lambda m: sum(2 * p.numel() if p.dim() > 1 else 4 * p.numel() for p in m.parameters())
+
+    def hook(m, inp, out):
+        total[0] += 2 * (inp[0].numel() + out.numel()) + pbytes(m)
+    hs = [m.register_forward_hook(hook) for m in model.modules()
+          if isinstance(m, (BasicBlock, Bottleneck)) or (isinstance(m, nn.Conv2d) and id(m) not in inside)]
+
+    def sum_hook(m, inp, out):                            # HighResolutionModule: out_i = relu(x_i + terms): base + each term at ITS resolution + out
+        for i, o in enumerate(out):
+            total[0] += 2 * 2 * o.numel()
+            for j in range(len(out)):
+                if j > i:                                 # 1x1 up-convolution's output, read through the nearest-neighbour upsample
+                    total[0] += 2 * o.numel() // (4 ** (j - i))
+                elif j < i:
+                    total[0] += 2 * o.numel()
+    hs += [m.register_forward_hook(sum_hook) for m in model.modules() if isinstance(m, HighResolutionModule)]
+    with torch.no_grad():
+        model.to('meta')(torch.empty((n_crops, 3, resolution[0], resolution[1]), device='meta'))
+    for h in hs:
+        h.remove()
+    return dict(bytes=total[0], flops=eng.count['flops'], launches=eng.count['launches'], bytes_as_executed=eng.count['bytes'])
 
 
 def fold_batchnorm(model):
@@ -292,13 +321,10 @@ class HRNetPose(object):
         # per count (a capture is a multi-100-ms stall); 1 = exact batch sizes
         self.graph_bucket = max(1, int(graph_bucket)) if use_graph else 1
         self._graphs = {}
-        # autotune: at the first replay of a crop count, capture the forward in each executor configuration (HipHRNet.CONFIGS), time a
-        # few replays of each on this device and keep the fastest -- which one wins depends on how the crop count's tiles quantise on
-        # the chip (hrnet_hip.py).  Off by default: results differ in the last bf16 bits between configurations (summation order),
-        # and a test that compares an eager forward with a replay needs both in ONE configuration.  FramePipeline / ivclabpose enable it.
+        # autotune: the executor configuration follows the crop count (config_for); off = one configuration for every count (results of
+        # different configurations differ in the last bf16 bits, and a test that compares an eager forward with a replay needs both in ONE)
         self.autotune = bool(autotune) and backend == 'hip' and use_graph
-        self.tuned = {}                                   # crop count -> {'choice': name, 'ms': {name: ms per replay}}
-        self._kept = []
+        self.tuned = {}                                   # crop count -> {'choice': configuration name} of every replay captured so far
         self._pools = {}             # graph memory pool per replay slot: graphs of ONE slot replay one after the other and may share
                                      # intermediates; the two slots of FramePipeline(pose_streams=2) replay concurrently and must not
         self.stream = torch.cuda.current_stream(self.device)
@@ -330,8 +356,6 @@ class HRNetPose(object):
         flight at the same time (FramePipeline(pose_streams=2)) use different slots of the same weights."""
         return self._run(x, 'features', slot)
 
-    plan_mode = int(os.environ.get('PAM_PLAN_MODE', '0'))      # 0: plans replay eagerly on real streams / events; 1: as one explicit hipGraph
-
     def _head(self, f):
         n, c, h, w = f.shape
         hm = torch.empty((n, self.head_w.shape[0], h, w), dtype=torch.float32, device=f.device, memory_format=torch.channels_last)
@@ -347,27 +371,10 @@ class HRNetPose(object):
         if not self.use_graph:
             with torch.no_grad():
                 return self._forward(x, kind)
-        if self.backend == 'hip' and self.hip.dag:
-            # the dependency-precise schedule as a LAUNCH PLAN (recorded once per crop count, replayed from C; csrc/pam_plan.hip) -- the
-            # captured-hipGraph form of that schedule crashes the ROCm 7.2 capture.  Measured slower than the joined schedule below
-            # (DESIGN section 4), so HipHRNet.dag is off by default.
-            g = self._graphs.get((n, 'features', slot))
-            if g is None:
-                static_in = torch.empty_like(x)
-                static_in.copy_(x)
-                with torch.no_grad():
-                    plan = self.hip.make_plan(static_in)
-                g = (plan, static_in, plan.out)
-                self._graphs[(n, 'features', slot)] = g
-            plan, static_in, static_out = g
-            if static_in.data_ptr() != x.data_ptr():
-                static_in.copy_(x)
-            plan.replay(self.plan_mode)
-            return static_out if kind == 'features' else self._head(static_out)
         g = self._graphs.get((n, kind, slot))
-        if g is None and self.autotune and kind == 'features':
-            g = self._autotune(x, slot)
         if g is None:
+            if self.backend == 'hip':
+                self.hip.apply_config(self.config_for(n))
             other = self._graphs.get((n, 'features' if kind == 'heatmaps' else 'heatmaps', slot))
             static_in = other[1] if other is not None else torch.empty_like(x)     # one input buffer per batch size and slot
             static_in.copy_(x)
@@ -407,34 +414,15 @@ class HRNetPose(object):
             self._pools[slot] = torch.cuda.graph_pool_handle()
         return self._pools[slot]
 
-    def _autotune(self, x, slot, reps=6):
-        """Capture the n-crop forward in every executor configuration, time `reps` replays of each (after two warm ones), keep the
-        fastest as the replay instance of (n, slot).  A second slot of an already tuned crop count reuses the choice."""
-        n = x.shape[0]
-        static_in = torch.empty_like(x)
-        static_in.copy_(x)
-        names = [self.tuned[n]['choice']] if n in self.tuned else list(self.hip.CONFIGS)
-        best, ms = None, {}
-        for name in names:
-            self.hip.apply_config(name)
-            g = self._capture(static_in, 'features', slot)
-            if len(names) > 1:
-                for _ in range(2):
-                    g[0].replay()
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record()
-                for _ in range(reps):
-                    g[0].replay()
-                b.record(); b.synchronize()
-                ms[name] = a.elapsed_time(b) / reps
-            self._kept.append(g[0])                       # the slower captures live as long as the network: _lib.track_graph
-            if best is None or (len(names) > 1 and ms[name] < ms[best[0]]):
-                best = (name, g)
-        if n not in self.tuned:
-            self.tuned[n] = {'choice': best[0], 'ms': ms}
-        self.hip.apply_config(best[0])                    # the executor stays in the configuration of its latest capture
-        self._graphs[(n, 'features', slot)] = best[1]
-        return best[1]
+    def config_for(self, n):
+        """Executor configuration of the n-crop forward (HipHRNet.CONFIGS).  With ``autotune`` a fixed rule from interleaved A/B runs over
+        crop counts (tools/ab_crops.sh, hrnet_hip.py): up to 12 crops the 96-channel branch runs as streamed convolutions (a 160-item fused
+        launch is a longer chain than it is worth on a nearly empty chip), from there both fine branches are fused.  (Round 3 timed every
+        configuration at the first replay of a crop count: 1.5 s per count, a choice decided by noise -- the configurations were 0.4-3 %
+        apart -- and three dead captures per count that could never be destroyed, see _lib.new_graph.)"""
+        name = 'resident48_streamed96' if (self.autotune and n <= 12) else type(self.hip).config_name
+        self.tuned[n] = {'choice': name}
+        return name
 
     def input_buffer(self, n, slot=0):
         """The (N,3,H,W) channels-last bf16 tensor the preprocessing kernel writes; the replay's own input when one

@@ -111,66 +111,49 @@ class PackedConv(object):
 
 
 class PackedBlock(object):
-    """One BasicBlock (conv3x3 -> ReLU -> conv3x3 -> + x -> ReLU) packed for ``pam_basic_block_nhwc_bf16``: the 2 * NCH weight
-    chunk images the kernel streams through LDS (layout: include/pam.h) and the [2][C] float32 bias."""
+    """One BasicBlock (conv3x3 -> ReLU -> conv3x3 -> + x -> ReLU) of the 48- or 96-channel branch packed for
+    ``pam_basic_block2_nhwc_bf16`` (csrc/pam_block2.hip; layouts: include/pam.h): ONE buffer ``wpack`` =
+    [float32 bias of conv1, conv2, padded to 1 KiB][k-step weight images of conv1][... of conv2]."""
 
     def __init__(self, conv1, conv2, device):
-        lib = _lib.load()
         c = conv1.weight.shape[0]
-        assert conv1.weight.shape == (c, c, 3, 3) and conv2.weight.shape == (c, c, 3, 3)
-        lay = (C.c_int32 * 5)()
-        if lib.pam_basic_block_chunk_layout(c, lay) != 0:
-            raise _lib.PamError('no fused-block kernel for %d channels' % c)
-        ks, nch, pwt, chb, nstep = [int(v) for v in lay]
-        assert pwt == 64 and chb == ks * c * 64 and nstep == ks * nch and nstep * 32 >= 9 * c, (ks, nch, pwt, chb, nstep)
-        def images(chan):
-            """[2][nch][ks][C rows][4 pieces][8]: row R of a k-step image = output channel chan[R], 16-byte pieces bank-swizzled."""
-            rows = torch.arange(c)
-            sigma = torch.tensor([0, 2, 3, 1])[(rows % 16) >> 2]                      # bank swizzle of the 16-byte pieces of a row
-            src = torch.arange(4)[None, :] ^ sigma[:, None]                            # physical piece p of row r holds logical piece p ^ sigma[r]
-            img = torch.zeros((2, nch, ks, c, 4, 8), dtype=torch.float32)
-            for cv, conv in enumerate((conv1, conv2)):
+        assert c in (48, 96) and conv1.weight.shape == (c, c, 3, 3) and conv2.weight.shape == (c, c, 3, 3)
+        rows = torch.arange(c)
+        zb = lambda cv: cv.bias.detach().float() if cv.bias is not None else torch.zeros(c)
+        head = torch.zeros(256, dtype=torch.float32)
+        head[:2 * c] = torch.cat([zb(conv1), zb(conv2)])
+        if c == 48:
+            # k_bblock2_48: K = (tap, cin) flattened, 14 k-steps of 32 (zero tail); a k-step image = [48 rows][4 pieces][8].  Row
+            # j * 16 + 4 q' + r = channel 8 q' + 4 j + r for N tiles j = 0, 1 and 32 + 4 q' + r for j = 2 (a lane ends with channels
+            # 8 g .. 8 g + 7 and 32 + 4 g .. + 3: aligned 16 + 8 bytes of a pixel); physical piece p of row R holds logical piece
+            # p ^ sigma[(R % 16) >> 2], sigma = (0, 2, 3, 1) (LDS bank swizzle)
+            nstep = 14
+            j, qq, r = rows // 16, (rows % 16) >> 2, rows & 3
+            chan = torch.where(j < 2, 8 * qq + 4 * j + r, 32 + 4 * qq + r)
+            src = torch.arange(4)[None, :] ^ torch.tensor([0, 2, 3, 1])[qq][:, None]
+            imgs = []
+            for conv in (conv1, conv2):
                 w = conv.weight.detach().float().permute(0, 2, 3, 1).reshape(c, 9 * c)[chan]       # [row][k = tap * C + cin]
                 wk = torch.zeros((c, nstep * 32), dtype=torch.float32)
                 wk[:, :9 * c] = w
-                wk = wk.reshape(c, nstep, 4, 8)                                        # [row][k-step][piece][8]
-                wk = torch.gather(wk, 2, src[:, None, :, None].expand(c, nstep, 4, 8))
-                img[cv] = wk.permute(1, 0, 2, 3).reshape(nch, ks, c, 4, 8)             # chunk = ks consecutive k-step sub-images [row][4][8]
-            return img
-        rows = torch.arange(c)
-        img = images(48 * (rows // 48) + 12 * ((rows % 16) >> 2) + 4 * ((rows % 48) // 16) + (rows & 3))
-        self.w_img = img.to(torch.bfloat16).to(device).contiguous()
-        zb = lambda cv: cv.bias.detach().float() if cv.bias is not None else torch.zeros(c)
-        self.bias = torch.stack([zb(conv1), zb(conv2)]).to(device).contiguous()
-        self.c = c
-        self.c1 = self.c2 = None            # the unfused PackedConv pair (fallback for shapes the fused kernel does not take)
-        # the resident-weights kernel (csrc/pam_block2.hip, C = 48) takes ONE buffer: [float32 bias padded to 1 KiB][conv1's k-step
-        # images][conv2's] -- the k-step images are the ones above
-        self.wpack = None
-        if c == 48:
-            # its rows: N tiles 0, 1 = channels 8 q' + 4 j + r, N tile 2 = 32 + 4 q' + r (q' = (R % 16) >> 2, r = R & 3): a lane ends with
-            # channels 8 g .. 8 g + 7 and 32 + 4 g .. + 3 -- aligned 16 + 8 bytes of a pixel
-            j, qq, r = rows // 16, (rows % 16) >> 2, rows & 3
-            chan2 = torch.where(j < 2, 8 * qq + 4 * j + r, 32 + 4 * qq + r)
-            head = torch.zeros(256, dtype=torch.float32)
-            head[:2 * c] = self.bias.reshape(-1).cpu()
-            self.wpack = torch.cat([head.view(torch.uint8), images(chan2).to(torch.bfloat16).reshape(-1).view(torch.uint8)]).to(device).contiguous()
-            assert self.wpack.numel() == 1024 + 2 * 14 * 48 * 64
-        elif c == 96:
-            # k_bblock2_96 streams k-step images [96 rows][4 pieces][8] in the order (conv, chunk of 32 input channels, tap); row j * 16 + q
-            # = output channel 24 * (q >> 2) + 4 * j + (q & 3) (a lane ends with 24 contiguous channels), physical piece p of row r holds the
-            # chunk's input channels 8 * (p ^ ((r >> 1) & 2)) .. + 7
-            chan96 = 24 * ((rows % 16) >> 2) + 4 * (rows // 16) + (rows & 3)
-            src96 = torch.arange(4)[None, :] ^ ((rows >> 1) & 2)[:, None]
+                wk = wk.reshape(c, nstep, 4, 8)                                                    # [row][k-step][piece][8]
+                imgs.append(torch.gather(wk, 2, src[:, None, :, None].expand(c, nstep, 4, 8)).permute(1, 0, 2, 3))
+            nbytes = 1024 + 2 * nstep * c * 64
+        else:
+            # k_bblock2_96: k-step images [96 rows][4 pieces][8] in the order (conv, chunk of 32 input channels, tap); row j * 16 + q =
+            # output channel 24 * (q >> 2) + 4 * j + (q & 3) (a lane ends with 24 contiguous channels), physical piece p of row r holds
+            # the chunk's input channels 8 * (p ^ ((r >> 1) & 2)) .. + 7
+            chan = 24 * ((rows % 16) >> 2) + 4 * (rows // 16) + (rows & 3)
+            src = torch.arange(4)[None, :] ^ ((rows >> 1) & 2)[:, None]
             imgs = []
             for conv in (conv1, conv2):
-                w = conv.weight.detach().float().permute(0, 2, 3, 1)[chan96]                  # [row][ky][kx][cin]
-                w = w.reshape(c, 9, 3, 4, 8).permute(2, 1, 0, 3, 4)                           # [chunk][tap][row][piece][8]
-                imgs.append(torch.gather(w, 3, src96[None, None, :, :, None].expand(3, 9, c, 4, 8)))
-            head = torch.zeros(256, dtype=torch.float32)
-            head[:2 * c] = self.bias.reshape(-1).cpu()
-            self.wpack = torch.cat([head.view(torch.uint8), torch.stack(imgs).to(torch.bfloat16).reshape(-1).view(torch.uint8)]).to(device).contiguous()
-            assert self.wpack.numel() == 1024 + 2 * 27 * 96 * 64
+                w = conv.weight.detach().float().permute(0, 2, 3, 1)[chan]                         # [row][ky][kx][cin]
+                w = w.reshape(c, 9, 3, 4, 8).permute(2, 1, 0, 3, 4)                                # [chunk][tap][row][piece][8]
+                imgs.append(torch.gather(w, 3, src[None, None, :, :, None].expand(3, 9, c, 4, 8)))
+            nbytes = 1024 + 2 * 27 * c * 64
+        self.wpack = torch.cat([head.view(torch.uint8), torch.stack(imgs).to(torch.bfloat16).reshape(-1).view(torch.uint8)]).to(device).contiguous()
+        assert self.wpack.numel() == nbytes
+        self.c = c
 
 
 class PackedTail(object):
@@ -206,30 +189,6 @@ class PackedTail(object):
                 im1[sl] = torch.gather(w, 1, cin.reshape(64, 64)).reshape(64, 8, 8)
             self.w1 = im1.to(torch.bfloat16).to(device).contiguous()
             self.b1 = zb(conv1_next).to(device).contiguous()
-
-
-class LaunchPlan(object):
-    """A recorded forward (pam_plan_*): ``replay`` issues it on the current stream (+ the plan's side streams); ``out`` is the static
-    output tensor.  Holds every tensor of the recorded forward alive: the launches carry their addresses."""
-
-    def __init__(self, lib, handle, keep, out, device):
-        self.lib, self.handle, self.keep, self.out, self.device = lib, handle, keep, out, device
-        info = (C.c_int32 * 4)()
-        lib.pam_plan_info(handle, info)
-        self.launches, self.events, self.streams, self.ops = [int(v) for v in info]
-
-    def replay(self, mode=0):
-        rc = self.lib.pam_plan_replay(self.handle, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), mode)
-        if rc != 0:
-            raise _lib.PamError('pam_plan_replay failed (%d): %s' % (rc, self.lib.pam_plan_last_error(self.handle).decode()))
-        return self.out
-
-    def __del__(self):
-        try:
-            if self.handle:
-                self.lib.pam_plan_destroy(self.handle); self.handle = None
-        except Exception:
-            pass
 
 
 class PackedPointwise64(object):
@@ -307,42 +266,10 @@ class ConvEngine(object):
                            2 * y.numel() * op.kh * op.kw * op.cin, launch)
         return y
 
-    def basic_blocks(self, ops, xs, waves=0):
-        """One launch: ops[i] (PackedBlock) applied to xs[i] (N, C, H, W channels-last bf16), for up to 4 independent tensors."""
-        assert 1 <= len(ops) == len(xs) <= _lib.PAM_BLOCK_MAX_BRANCHES
-        ys = []
-        descs = (_lib.PamBlockDesc * len(ops))()
-        for k, (op, x) in enumerate(zip(ops, xs)):
-            n, c, h, w = x.shape
-            assert c == op.c and (x.device.type == 'meta' or x.is_contiguous(memory_format=torch.channels_last)), (x.shape, op.c)
-            y = torch.empty_like(x)
-            ys.append(y)
-            if self._keep is not None:
-                self._keep.append(y)
-            if self.count is not None:       # unique bytes: input + both weight sets + biases + output (the residual is the input)
-                self.count['bytes'] += 2 * (x.numel() + y.numel() + 2 * 9 * c * c) + 8 * c
-                self.count['flops'] += 2 * 2 * y.numel() * 9 * c
-            if x.device.type != 'meta':
-                descs[k].in_ = x.data_ptr(); descs[k].w_img = op.w_img.data_ptr(); descs[k].bias = op.bias.data_ptr()
-                descs[k].out = y.data_ptr(); descs[k].N = n; descs[k].H = h; descs[k].W = w; descs[k].C = c
-        if self.count is not None:
-            self.count['launches'] += 1
-        if xs[0].device.type == 'meta':
-            return ys
-        launch = lambda: self.lib.pam_basic_block_nhwc_bf16_ex(C.c_void_p(torch.cuda.current_stream(xs[0].device).cuda_stream), len(ops),
-                                                                C.cast(descs, C.c_void_p), waves)
-        rc = launch()
-        if rc != 0:
-            raise _lib.PamError('pam_basic_block_nhwc_bf16 failed (%d) for %s' % (rc, [tuple(x.shape) for x in xs]))
-        self._prof_add(xs[0], 'k_bblock C=' + '+'.join(str(o.c) for o in ops), tuple(tuple(x.shape) for x in xs),
-                       sum(2 * (2 * x.numel() + 2 * 9 * o.c * o.c) + 8 * o.c for o, x in zip(ops, xs)),
-                       sum(2 * 2 * x.numel() * 9 * o.c for o, x in zip(ops, xs)), launch)
-        return ys
-
     def basic_block2(self, op, x, tile=None):
         """One BasicBlock (PackedBlock with ``wpack``: C = 48) on x through the resident-weights kernel; tile = (rows, cols) or None."""
         n, c, h, w = x.shape
-        assert c == op.c and op.wpack is not None, (x.shape, op.c)
+        assert c == op.c, (x.shape, op.c)
         y = torch.empty_like(x)
         if self._keep is not None:
             self._keep.append(y)
@@ -448,72 +375,6 @@ class ConvEngine(object):
         self._prof_add(base, 'k_upsample_add', (n, h, w, c, len(terms)), 2 * (2 * base.numel() + sum(t.numel() for t in terms)), 0, launch)
         return y
 
-    def conv_group(self, specs):
-        """One launch for several small independent convolutions.  specs: [(op, x, relu, relu_from)], x possibly a channel slice of a
-        wider channels-last tensor; returns the outputs in order."""
-        ys, descs = [], []
-        for op, x, relu, relu_from in specs:
-            n, cin, h, w = x.shape
-            in_cs = cin if x.device.type == 'meta' else x.stride(3)
-            assert cin == op.cin and op.cout % 48 == 0, (x.shape, op.cin, op.cout)
-            ho = (h + 2 * op.pad - op.kh) // op.stride + 1
-            wo = (w + 2 * op.pad - op.kw) // op.stride + 1
-            y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-            ys.append(y)
-            if self._keep is not None:
-                self._keep.append(y)
-            if self.count is not None:
-                self.count['bytes'] += 2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin) + 4 * op.cout
-                self.count['flops'] += 2 * y.numel() * op.kh * op.kw * op.cin
-            if x.device.type != 'meta':
-                d = _lib.PamConvDesc()
-                d.in_ = x.data_ptr(); d.w_packed = op.w.data_ptr(); d.bias = op.bias.data_ptr(); d.residual = None; d.out = y.data_ptr()
-                d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW = n, h, w, op.cin, op.cout, op.kh, op.kw
-                d.stride, d.pad, d.relu, d.in_cstride, d.relu_from = op.stride, op.pad, 1 if relu else 0, in_cs, relu_from
-                descs.append(d)
-        if specs and specs[0][1].device.type != 'meta':
-            st = torch.cuda.current_stream(specs[0][1].device).cuda_stream
-        for i in range(0, len(specs), _lib.PAM_CONV_GROUP_MAX):
-            if self.count is not None:
-                self.count['launches'] += 1
-            if specs[0][1].device.type == 'meta':
-                continue
-            part = descs[i:i + _lib.PAM_CONV_GROUP_MAX]
-            arr = (_lib.PamConvDesc * len(part))(*part)
-            rc = self.lib.pam_conv2d_group_nhwc_bf16(C.c_void_p(st), len(part), C.cast(arr, C.c_void_p))
-            if rc != 0:
-                raise _lib.PamError('pam_conv2d_group_nhwc_bf16 failed (%d)' % rc)
-        return ys
-
-    def upsample_add_group(self, specs):
-        """One launch for all sums of a fuse layer.  specs: [(base, terms, shifts, relu)]."""
-        ys, descs = [], []
-        for base, terms, shifts, relu in specs:
-            n, c, h, w = base.shape
-            y = torch.empty_like(base)
-            ys.append(y)
-            if self._keep is not None:
-                self._keep.append(y)
-            if self.count is not None:
-                self.count['bytes'] += 2 * (2 * base.numel() + sum(t.numel() for t in terms))
-            if base.device.type != 'meta':
-                d = _lib.PamUpDesc()
-                d.base = base.data_ptr(); d.out = y.data_ptr(); d.n_terms = len(terms)
-                for k, t in enumerate(terms):
-                    d.terms[k] = t.data_ptr(); d.shifts[k] = shifts[k]; d.term_cstrides[k] = t.stride(3)
-                d.N, d.H, d.W, d.C, d.relu = n, h, w, c, 1 if relu else 0
-                descs.append(d)
-        if self.count is not None:
-            self.count['launches'] += 1
-        if specs[0][0].device.type == 'meta':
-            return ys
-        st = torch.cuda.current_stream(specs[0][0].device).cuda_stream
-        arr = (_lib.PamUpDesc * len(descs))(*descs)
-        rc = self.lib.pam_upsample_add_group_nhwc_bf16(C.c_void_p(st), len(descs), C.cast(arr, C.c_void_p))
-        if rc != 0:
-            raise _lib.PamError('pam_upsample_add_group_nhwc_bf16 failed (%d)' % rc)
-        return ys
-
     def upsample_concat(self, a, b):
         """Darknet upsample(x2) + route: concat(nearest_up2(a), b) along channels."""
         n, ca, h2, w2 = a.shape
@@ -572,11 +433,8 @@ class HipHRNet(ConvEngine):
     def _module(self, hm):
         P = lambda c: PackedConv(c, self.device)
         branches = [[(P(b.conv1), P(b.conv2)) for b in br] for br in hm.branches]
-        # the same blocks packed for the fused kernel (one launch per block, or per block LEVEL over several branches)
-        lib = _lib.load()
-        lay = (C.c_int32 * 5)()
-        fused = [[PackedBlock(b.conv1, b.conv2, self.device) for b in br] if lib.pam_basic_block_chunk_layout(br[0].conv1.out_channels, lay) == 0 else None
-                 for br in hm.branches]
+        # the same blocks packed for the fused kernels (48- and 96-channel branches: one launch per block)
+        fused = [[PackedBlock(b.conv1, b.conv2, self.device) for b in br] if br[0].conv1.out_channels in (48, 96) else None for br in hm.branches]
         fuse = []
         for i, row in enumerate(hm.fuse_layers):
             r = []
@@ -624,26 +482,14 @@ class HipHRNet(ConvEngine):
     #   * a join before every stage (the new branch's transition conv reads another stream's sum) and at the end.
     # Every tensor of a forward is kept alive until the forward has been issued (self._keep), so the caching allocator can never
     # hand a block that another stream still reads to a new tensor.
-    lane_of = (0, 1, 2, 3)      # stream of branch b (0 = the caller's stream); issue order of the branches inside a module
-    order = (0, 1, 2, 3)
-    fuse_blocks = True          # BasicBlocks of the branches the fused kernel takes: one grouped launch per block level (caller's stream)
-    fuse_max_branches = None    # ... at most this many leading branches; None = 2: branches 0 and 1 (C = 48 and 96) as ONE grouped launch per block
-                                # level.  Round 3, interleaved A/B on one device (tools/ab_flags.py; 1 / 2 / 3 branches, or no fused block at
-                                # all, against the round-2 rule "1 below 96 crops, 3 from there"): 20 crops 2 -> -1.6 ... -1.9 %, none -0.7 ... -2.2 %,
-                                # 3 -> +8.9 %; 28 crops 2 -> -2.7 %; 60 crops 2 -> +1.0 %, none -1.0 %; 112 crops 2 -> -2.2 %; 217 crops 2 -> -2.3 %
-    fuse_waves = 8              # workgroup shape of the fused kernel (8 waves, one workgroup per CU, measured faster than 2 x 4 waves)
-    group_fuse = False          # True: fuse layers as one launch per LEVEL of convolutions over all branches + one launch for all sums
-                                # (99 launches per forward instead of 263, but the fuse convolutions no longer run beside the coarse
-                                # branches' chains: 3.50 ms vs 3.21 ms at 20 crops)
+    order = (0, 1, 2, 3)        # issue order of the branches inside a module (six orders measured within 1 %)
 
     def _stream(self, b):
-        l = self.lane_of[b]
-        return None if (l == 0 or not self.multi_stream) else self.side[l - 1]
+        """stream of branch b: the caller's for branch 0, side stream b - 1 otherwise"""
+        return None if (b == 0 or not self.multi_stream) else self.side[b - 1]
 
     def _barrier(self):
         """Join and re-fork all branch streams through the caller's stream."""
-        if self.plan_rec:
-            return                                      # a plan forks its side streams at the start of a replay and joins them at the end
         if self.multi_stream:
             cur = torch.cuda.current_stream(self.device)
             for st in self.side:
@@ -651,284 +497,60 @@ class HipHRNet(ConvEngine):
             for st in self.side:
                 st.wait_stream(cur)
 
-    # ---- dependency-precise schedule (dag = True) -------------------------------------------------------------------------------
-    # Instead of joining all branch streams once per module, every tensor that crosses streams carries the event recorded behind its
-    # producer, and a consumer stream waits for exactly the tensors it reads: sum i waits only for ITS terms and branch i of the next
-    # module starts behind sum i, while other branches' chains and fuse convolutions are still running.  Captured into the hipGraph these
-    # waits are plain edges.  (All side streams are forked from the caller's stream at the start of the forward and joined at its end.)
-    dag = False                 # measured: 2.68 ms (plan, eager replay) vs 2.61 ms (one join per module, captured hipGraph) at 20 crops, same box
-
-    # Executor configurations the replay autotuner chooses between per crop count (HRNetPose(autotune=True)): which of them is fastest
-    # depends on how a crop count's tile counts quantise on 256 CUs -- interleaved A/B, one device, vs 'grouped': 20 crops 'streamed96'
-    # -2.8 %, 'unfused' -0.4 %; 28 crops 0 / +1.1 %; 40 crops +2.2 / +1.3 %; 60 crops -0.6 / -2.9 %; 112 crops +4.1 %; 217 crops +6.6 %.
+    # Executor configurations the replay autotuner chooses between per crop count (HRNetPose(autotune=True)).  Round 4, interleaved A/B on
+    # one device (tools/ab_crops.sh; vs round 3's grouped ring-kernel blocks, which are gone): 12 crops resident48_streamed96 -9.2 %,
+    # fused48_fused96 -8.2 %; 20 crops -3.3 / -7.3 %; 40 crops -4.1 / -8.9 %; 60 crops -5.7 / -11.2 %; 112 crops -1.7 / -7.6 %; 217 crops
+    # +0.3 / -6.9 %.
     CONFIGS = {
-        'grouped': dict(fuse_blocks=True, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=0),      # branches 0 + 1 as one fused-BasicBlock launch per level
-        'unfused': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=0),     # one launch per convolution, 96-channel branch on k_conv3x3
-        'streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=0),  # ... 96-channel branch on k_conv3x3s (48-channel slabs)
-        'fused48_streamed96': dict(fuse_blocks=True, fuse_max_branches=1, c96_slab=48, fuse_short=0, block2=0),   # branch 0 fused alone (ring kernel), branch 1 streamed
-        'resident48_streamed96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=1),   # branch 0 on the resident-weights fused block
-        'resident48': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=0, fuse_short=0, block2=1),
-        'resident48_wide96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=96, fuse_short=0, block2=1),         # ... 96-channel slabs: the patch is fetched once
-        'fused48_fused96': dict(fuse_blocks=False, fuse_max_branches=2, c96_slab=48, fuse_short=0, block2=3),           # both fine branches on the new fused blocks
+        'fused48_fused96': dict(block2=3, c96_slab=48),              # both fine branches: ONE fused-BasicBlock launch per block (csrc/pam_block2.hip)
+        'resident48_streamed96': dict(block2=1, c96_slab=48),        # 48-channel branch fused, 96-channel branch as two streamed convolutions per block
     }
-    fuse_short = 0              # bit b: grouped branch b runs as "short" 4-row items (pam_basic_block_nhwc_bf16_ex, bits 4-7 of `waves`): meant to
-                                # pack the grouped launch better (360 items of 22-29 us on 256 CUs), measured SLOWER alone (47.7-47.9 vs 41.0 us
-                                # per grouped 48 + 96 block at 20 crops: more halo rows, fewer M tiles per weight fragment) -- not a tuner candidate
 
     def apply_config(self, name):
         for k, v in self.CONFIGS[name].items():
             setattr(self, k, v)
         self.config_name = name
 
-    config_name = 'grouped'
-
-    plan_rec = False            # True while a launch plan is being recorded (make_plan): stream switches, event records and waits go to
-                                # pam_plan_* instead of torch streams / events, launches are stored by the library instead of issued
-
-    @contextlib.contextmanager
-    def _on(self, b):
-        """Everything issued inside runs on branch stream b."""
-        if self.plan_rec:
-            prev, lane = self._plan_cur, (self.lane_of[b] if self.multi_stream else 0)
-            self.lib.pam_plan_stream(lane); self._plan_cur = lane
-            try:
-                yield
-            finally:
-                self.lib.pam_plan_stream(prev); self._plan_cur = prev
-        else:
-            with torch.cuda.stream(self._stream(b)):
-                yield
-
-    def make_plan(self, x8):
-        """Record the forward on x8 (a static input buffer) as a launch plan (csrc/pam_plan.hip) -> LaunchPlan; its ``out`` is the
-        static output tensor every replay fills."""
-        assert self.dag and not self.group_fuse and self.prof is None
-        rc = self.lib.pam_plan_begin()
-        if rc != 0:
-            raise _lib.PamError('pam_plan_begin failed (%d)' % rc)
-        self.plan_rec, self._plan_cur = True, 0
-        try:
-            self._keep, self._evt = [], {}
-            out = self._features(x8)
-        except Exception:
-            self.lib.pam_plan_abort()
-            raise
-        finally:
-            self.plan_rec = False
-        h = C.c_void_p()
-        rc = self.lib.pam_plan_end(C.byref(h))
-        if rc != 0:
-            raise _lib.PamError('pam_plan_end failed (%d)' % rc)
-        keep, self._keep = self._keep + [x8], []
-        return LaunchPlan(self.lib, h, keep, out, self.device)
-
-    def _sobj(self, b):
-        l = self.lane_of[b]
-        return torch.cuda.current_stream(self.device) if (l == 0 or not self.multi_stream) else self.side[l - 1]
-
-    def _mark(self, t, b):
-        """t was just produced on branch stream b."""
-        if self.plan_rec:
-            if self.multi_stream:
-                prev, lane = self._plan_cur, self.lane_of[b]
-                self.lib.pam_plan_stream(lane)
-                self._evt[id(t)] = (self.lib.pam_plan_record(), lane, t)
-                self.lib.pam_plan_stream(prev)
-        elif self.multi_stream:
-            ev = torch.cuda.Event()
-            ev.record(self._sobj(b))
-            self._evt[id(t)] = (ev, self.lane_of[b], t)       # the tensor is kept so that its id cannot be reused within the forward
-
-    def _need(self, t, b):
-        """branch stream b is about to read t."""
-        if self.multi_stream:
-            e = self._evt.get(id(t))
-            if e is not None and e[1] != self.lane_of[b]:
-                if self.plan_rec:
-                    prev = self._plan_cur
-                    self.lib.pam_plan_stream(self.lane_of[b]); self.lib.pam_plan_wait(e[0]); self.lib.pam_plan_stream(prev)
-                else:
-                    self._sobj(b).wait_event(e[0])
-
-    def _hr_module_dag(self, mod, xs):
-        xs = list(xs)
-        fuse = mod['fuse']
-        nb = len(mod['branches'])
-        terms = [dict() for _ in fuse]                    # terms[i][j] = (tensor or channel slice, shift, base tensor that carries the event)
-        n0 = (xs[0][2] if isinstance(xs[0], tuple) else xs[0]).shape[0]
-        fmax = self.fuse_max_branches if self.fuse_max_branches is not None else 2
-        grouped = []
-        if self.fuse_blocks:
-            for b in range(nb):
-                shp = xs[b][2].shape if isinstance(xs[b], tuple) else xs[b].shape
-                cb = mod['branches'][b][0][0].cin
-                hb, wb = (shp[2], shp[3]) if not isinstance(xs[b], tuple) else ((shp[2] + 2 - 3) // xs[b][1].stride + 1, (shp[3] + 2 - 3) // xs[b][1].stride + 1)
-                if mod['fused'][b] is not None and len(grouped) == b and len(grouped) < min(fmax, _lib.PAM_BLOCK_MAX_BRANCHES) and \
-                        self.lib.pam_basic_block_rows(cb, hb, wb, 0) > 0:
-                    grouped.append(b)
-
-        def transition(b):
-            if isinstance(xs[b], tuple):                  # a branch this stage creates: its transition conv runs on its own stream
-                with self._on(b):
-                    self._need(xs[b][2], b)
-                    xs[b] = self.conv(xs[b][1], xs[b][2], relu=True)
-                    self._mark(xs[b], b)
-        if grouped:                                       # one grouped launch per block level on the caller's stream (= branch 0's)
-            for b in grouped:
-                transition(b)
-            for b in grouped:
-                self._need(xs[b], 0)
-            ys = [xs[b] for b in grouped]
-            for k in range(len(mod['fused'][0])):
-                ys = self.basic_blocks([mod['fused'][b][k] for b in grouped], ys, self.fuse_waves | ((self.fuse_short & ((1 << len(grouped)) - 1)) << 4))
-            for b, y in zip(grouped, ys):
-                xs[b] = y
-                self._mark(y, 0)
-        for b in [q for q in self.order if q < nb]:
-            blocks = mod['branches'][b] if b not in grouped else []
-            transition(b)
-            with self._on(b):
-                x = xs[b]
-                self._need(x, b)
-                x = self._branch_blocks(mod, b, blocks, x)
-                xs[b] = x
-                # the 1x1 up-convolutions first: they feed the FINER outputs, whose next chains are the longest
-                mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up) else None
-                if mu is not None:
-                    y = self.conv(mu['op'], x)
-                    self._mark(y, b)
-                    for i, off, c, sh in mu['parts']:
-                        terms[i][b] = (y[:, off:off + c], sh, y)
-                for i, row in enumerate(fuse):
-                    f = row[b] if b < len(row) else None
-                    if f is not None and f[0] == 'up' and mu is None:
-                        y = self.conv(f[1], x)
-                        self._mark(y, b)
-                        terms[i][b] = (y, f[2], y)
-                mg = mod['merged'].get(b) if self.merge_fuse else None
-                heads = {}
-                if mg is not None:                        # first conv of all down chains from this branch in one launch
-                    yh = self.conv(mg['op'], x, relu=True, relu_from=mg['relu_from'])
-                    self._mark(yh, b)
-                    heads = {i: yh[:, off:off + c] for i, off, c, _ in mg['parts']}
-                for i, row in enumerate(fuse):
-                    f = row[b] if b < len(row) else None
-                    if f is None or f[0] == 'up':
-                        continue
-                    t, ops = (heads[i], f[1][1:]) if i in heads else (x, f[1])
-                    k0 = len(f[1]) - len(ops)
-                    base = yh if (i in heads and not ops) else None
-                    for k, op in enumerate(ops):
-                        t = self.conv(op, t, relu=(k0 + k < len(f[1]) - 1))
-                    if base is None:
-                        self._mark(t, b); base = t
-                    terms[i][b] = (t, 0, base)
-        # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order, on stream i
-        out = [None] * len(fuse)
-        for i in [q for q in self.order if q < len(fuse)]:
-            with self._on(i):
-                self._need(xs[i], i)
-                tl = [terms[i][j] for j in sorted(terms[i])]
-                for _, _, base in tl:
-                    self._need(base, i)
-                out[i] = self.upsample_add(xs[i], [t for t, _, _ in tl], [sh for _, sh, _ in tl], relu=True) if tl else torch.relu(xs[i])
-                self._mark(out[i], i)
-        return out
-
+    config_name = 'fused48_fused96'
+    block2 = 3                  # bit 0: 48-channel branch as one resident-weights fused BasicBlock launch per block (k_bblock2_48), bit 1: the
+                                # 96-channel branch on the streamed-weights fused block (k_bblock2_96) -- csrc/pam_block2.hip
+    c96_slab = 48               # 96 -> 96 layers that are NOT fused: k_conv3x3s with 48-channel slabs (0 = k_conv3x3)
     stamp = None                # diagnostics (tools/fwd_stamps.py): callable(tag) issued on the current stream at points of the schedule
+    knock_out = 0               # diagnostics: bit b = skip the BasicBlocks of branch b (what a free branch would be worth: tools/ab_flags.py)
 
     def _st(self, tag):
         if self.stamp is not None:
             self.stamp(tag)
 
-    knock_out = 0               # diagnostics: bit b = skip the BasicBlocks of branch b (what would a free branch be worth)
-    block2 = 0                  # bit 0: 48-channel branch as one resident-weights fused BasicBlock launch per block (k_bblock2_48), bit 1: the
-                                # 96-channel branch on the streamed-weights fused block (k_bblock2_96) -- csrc/pam_block2.hip
-
     def _branch_blocks(self, mod, b, blocks, x):
-        """The BasicBlocks of branch b that no grouped launch took, on the current stream."""
+        """The BasicBlocks of branch b on the current stream."""
         fused = mod['fused'][b]
-        if self.knock_out & (1 << b):                   # diagnostics (tools/ab_flags.py): the branch's blocks are not issued at all
+        if self.knock_out & (1 << b):
             return x
-        # staggered start: this branch's chain begins behind block k of branch 0 (a fork-style edge from the caller's stream, the one
-        # cross-stream dependency hipGraph capture takes on ROCm 7.2) -- see `stagger`
-        nb = len(mod['branches'])
-        k = self.stagger.get(nb, ())[b] if (self.multi_stream and not self.plan_rec and b < len(self.stagger.get(nb, ()))) else 0
-        if b > 0 and k > 0 and x.device.type == 'cuda' and len(self._b0_events) >= k:
-            torch.cuda.current_stream(self.device).wait_event(self._b0_events[k - 1])
-        if b == 0:
-            self._b0_events = []
-
-        def done():
-            if b == 0 and self.multi_stream and not self.plan_rec and x.device.type == 'cuda' and any(self.stagger.get(nb, ())):
-                ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream(self.device)); self._b0_events.append(ev)
-        if self.block2 and blocks and fused is not None and fused[0].wpack is not None and (self.block2 & (1 if fused[0].c == 48 else 2)):
+        if blocks and fused is not None and (self.block2 & (1 if fused[0].c == 48 else 2)):
             for op in fused:
-                x = self.basic_block2(op, x); done()
+                x = self.basic_block2(op, x)
             return x
         for c1, c2 in blocks:
             y = self.conv(c1, x, relu=True)
-            x = self.conv(c2, y, res=x, relu=True); done()
+            x = self.conv(c2, y, res=x, relu=True)
         return x
 
-    # Which branch finishes last decides how much of a module's fuse layer is exposed: the strided-conv chains hang off the FINE
-    # branches (from branch 0: up to three dependent convolutions), the coarsest branch only feeds 1x1 up-convolutions.  Sharing the
-    # chip fairly, the four chains end together and the longest tail runs on an idle chip (un-profiled timeline: tools/fwd_stamps.py).
-    # stagger[nb][b] = k: in a module of nb branches, branch b starts behind block k of branch 0 (0 = at once), so the coarse branches
-    # end last and the fine branches' tails run beside them.
-    stagger = {}
-    _b0_events = ()
-
     def _hr_module(self, mod, xs):
-        """xs[b]: tensor, or ('lazy', transition op, source tensor) for a branch this stage creates."""
-        if self.dag and not self.group_fuse:
-            return self._hr_module_dag(mod, xs)
+        """xs[b]: tensor, or ('lazy', transition op, source tensor) for a branch this stage creates.
+        Stream b runs branch b's blocks and the fuse chains that hang off its output; ONE join; sum i on stream i."""
         xs = list(xs)
         fuse = mod['fuse']
         terms = [dict() for _ in fuse]
-        # which leading branches go through the fused, grouped kernel (shape supported by pam_basic_block_rows)
-        grouped = []
-        if self.fuse_blocks and xs[0] is not None:
-            n0 = (xs[0][2] if isinstance(xs[0], tuple) else xs[0]).shape[0]
-            fmax = self.fuse_max_branches if self.fuse_max_branches is not None else 2
-            for b in range(len(mod['branches'])):
-                shp = xs[b][2].shape if isinstance(xs[b], tuple) else xs[b].shape
-                cb = mod['branches'][b][0][0].cin
-                hb, wb = (shp[2], shp[3]) if not isinstance(xs[b], tuple) else ((shp[2] + 2 - 3) // xs[b][1].stride + 1, (shp[3] + 2 - 3) // xs[b][1].stride + 1)
-                if mod['fused'][b] is not None and len(grouped) == b and len(grouped) < min(fmax, _lib.PAM_BLOCK_MAX_BRANCHES) and \
-                        self.lib.pam_basic_block_rows(cb, hb, wb, 0) > 0:
-                    grouped.append(b)
-        if grouped:
-            cur = torch.cuda.current_stream(self.device) if self.multi_stream else None
-            for b in grouped:                                         # transition convs of new branches: own stream, joined below
-                if isinstance(xs[b], tuple):
-                    with torch.cuda.stream(self._stream(b)):
-                        xs[b] = self.conv(xs[b][1], xs[b][2], relu=True)
-            if self.multi_stream:
-                for b in grouped:                                     # the branch streams hold the previous sums / transitions
-                    if self._stream(b) is not None:
-                        cur.wait_stream(self._stream(b))
-            ys = [xs[b] for b in grouped]
-            for k in range(len(mod['fused'][0])):
-                ys = self.basic_blocks([mod['fused'][b][k] for b in grouped], ys, self.fuse_waves | ((self.fuse_short & ((1 << len(grouped)) - 1)) << 4))
-            for b, y in zip(grouped, ys):
-                xs[b] = y
-            if self.multi_stream:
-                for b in grouped:
-                    if self._stream(b) is not None:
-                        self._stream(b).wait_stream(cur)
         for b in [q for q in self.order if q < len(mod['branches'])]:
-            blocks = mod['branches'][b] if b not in grouped else []
             with torch.cuda.stream(self._stream(b)):
                 x = xs[b]
                 if isinstance(x, tuple):                              # transition conv runs on the new branch's own stream
                     x = self.conv(x[1], x[2], relu=True)
                 self._st('b%d start' % b)
-                x = self._branch_blocks(mod, b, blocks, x)
+                x = self._branch_blocks(mod, b, mod['branches'][b], x)
                 self._st('b%d blocks' % b)
                 xs[b] = x
-                if self.group_fuse:
-                    continue
                 mg = mod['merged'].get(b) if self.merge_fuse else None
                 heads = {}
                 if mg is not None:                                    # first conv of all down chains from this branch in one launch
@@ -952,8 +574,6 @@ class HipHRNet(ConvEngine):
                             t = self.conv(op, t, relu=(k0 + k < len(f[1]) - 1))
                         terms[i][b] = (t, 0)
                 self._st('b%d tail' % b)
-        if self.group_fuse:
-            return self._fuse_grouped(mod, xs)
         self._barrier()
         self._st('join')
         # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order
@@ -965,78 +585,9 @@ class HipHRNet(ConvEngine):
                 self._st('sum%d' % i)
         return out
 
-    def _fuse_grouped(self, mod, xs):
-        """The fuse layer as grouped launches on the caller's stream: level 1 = every 1x1 up-convolution and the first strided
-        convolution of every down chain (per source branch these are already merged along Cout), level 2, 3 = the chains' next
-        convolutions, then ONE launch for the sums of all outputs.  Joins the branch streams before and re-forks them after."""
-        fuse = mod['fuse']
-        nb = len(mod['branches'])
-        if self.multi_stream:
-            cur = torch.cuda.current_stream(self.device)
-            for st in self.side:
-                cur.wait_stream(st)
-        terms = [dict() for _ in fuse]
-        pending = []                                                   # (target i, source b, remaining ops, index of the next op, chain length)
-        specs, sinks = [], []                                          # sinks[k](y): what to do with output k of this level
-        for b in range(nb):
-            x = xs[b]
-            mg = mod['merged'].get(b) if self.merge_fuse else None
-            heads_done = set()
-            if mg is not None:
-                def sink(y, mg=mg, b=b):
-                    for i, off, c, final in mg['parts']:
-                        t = y[:, off:off + c]
-                        f = fuse[i][b]
-                        if final:
-                            terms[i][b] = (t, 0)
-                        else:
-                            pending.append((i, b, t, f[1], 1))
-                specs.append((mg['op'], x, True, mg['relu_from'])); sinks.append(sink)
-                heads_done = {i for i, _, _, _ in mg['parts']}
-            mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up) else None
-            if mu is not None:
-                def sink_up(y, mu=mu, b=b):
-                    for i, off, c, sh in mu['parts']:
-                        terms[i][b] = (y[:, off:off + c], sh)
-                specs.append((mu['op'], x, False, 0)); sinks.append(sink_up)
-            for i, row in enumerate(fuse):
-                f = row[b] if b < len(row) else None
-                if f is None or (f[0] == 'up' and mu is not None) or (f[0] == 'down' and i in heads_done):
-                    continue
-                if f[0] == 'up':
-                    specs.append((f[1], x, False, 0)); sinks.append(lambda y, i=i, b=b, sh=f[2]: terms[i].__setitem__(b, (y, sh)))
-                else:
-                    ops = f[1]
-                    if len(ops) == 1:
-                        specs.append((ops[0], x, False, 0)); sinks.append(lambda y, i=i, b=b: terms[i].__setitem__(b, (y, 0)))
-                    else:
-                        specs.append((ops[0], x, True, 0)); sinks.append(lambda y, i=i, b=b, ops=ops: pending.append((i, b, y, ops, 1)))
-        while specs:
-            for y, sk in zip(self.conv_group(specs), sinks):
-                sk(y)
-            specs, sinks, nxt = [], [], pending
-            pending = []
-            for i, b, t, ops, k in nxt:
-                last = k == len(ops) - 1
-                specs.append((ops[k], t, not last, 0))
-                if last:
-                    sinks.append(lambda y, i=i, b=b: terms[i].__setitem__(b, (y, 0)))
-                else:
-                    sinks.append(lambda y, i=i, b=b, ops=ops, k=k: pending.append((i, b, y, ops, k + 1)))
-        sums = []
-        for i in range(len(fuse)):
-            tl = [terms[i][j] for j in sorted(terms[i])]
-            sums.append((xs[i], [t for t, _ in tl], [sh for _, sh in tl], True))
-        out = self.upsample_add_group(sums)
-        if self.multi_stream:
-            for st in self.side:
-                st.wait_stream(cur)
-        return out
-
     def features(self, x8):
         """x8: (N, 8, H, W) channels-last bf16 (RGB + 5 zero channels) -> (N, 48, H/4, W/4) channels-last bf16."""
         self._keep = []
-        self._evt = {}
         return self._features(x8)
 
     fuse_tail = True            # layer1: conv3 + residual + next conv1 of every Bottleneck in one launch (csrc/pam_pw.hip)
@@ -1044,7 +595,7 @@ class HipHRNet(ConvEngine):
     stop_after = None           # diagnostics (tools/stage_times.py): 'stem' | 'layer1' | 'stage2' | 'stage3' -> the forward ends there
 
     def _end(self, xs):
-        if self.multi_stream and not self.plan_rec:                                         # final join only (no re-fork: capture must end with no forked stream)
+        if self.multi_stream:                                                                # final join only (no re-fork: capture must end with no forked stream)
             cur = torch.cuda.current_stream(self.device)
             for st in self.side:
                 cur.wait_stream(st)
@@ -1072,24 +623,19 @@ class HipHRNet(ConvEngine):
                 x = self.conv(b['c3'], y, res=r, relu=True)
         if self.stop_after == 'layer1':
             return x
-        dag = self.dag and not self.group_fuse
         self._barrier()                                               # fork: branch streams must see layer1's output
-        if dag:
-            self._mark(x, 0)
         xs = [('lazy', self.t1[0], x), ('lazy', self.t1[1], x)]
         for m in self.stage2:
             xs = self._hr_module(m, xs)
         if self.stop_after == 'stage2':
             return self._end(xs)
-        if not dag:
-            self._barrier()                                           # the new branch's stream reads the last sum of stage 2
+        self._barrier()                                               # the new branch's stream reads the last sum of stage 2
         xs = xs + [('lazy', self.t2, xs[-1])]
         for m in self.stage3:
             xs = self._hr_module(m, xs)
         if self.stop_after == 'stage3':
             return self._end(xs)
-        if not dag:
-            self._barrier()
+        self._barrier()
         xs = xs + [('lazy', self.t3, xs[-1])]
         for m in self.stage4:
             xs = self._hr_module(m, xs)

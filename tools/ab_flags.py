@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of executor variants in ONE process on one device (guide rule 24): each variant = HipHRNet attribute overrides,
-replayed as a captured hipGraph (joined schedule) or a launch plan (dag); R rounds of `iters` replays each, medians and minima.
-usage: ab_flags.py [--n 20] name:attr=val,attr=val ...     e.g.  base: tail:fuse_tail=0 dag0:dag=1,form=plan0"""
+replayed as a captured hipGraph; R rounds of `iters` replays each, medians and minima.
+usage: ab_flags.py [--n 20] name:attr=val,attr=val ...     e.g.  base: r48:block2=1 no1:knock_out=2"""
 import os, sys, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,19 +17,10 @@ for v in args.variants:
     name, _, spec = v.partition(':')
     net = hrnet.HRNetPose(48, 17, None, use_graph=False)
     hip = net.hip
-    hip.dag = False
-    form = 'graph'
-    opts = []
     for kv in [q for q in spec.split(',') if q]:
         k, _, val = kv.partition('=')
-        if k == 'form':
-            form = val
-        elif k.startswith('opt'):                        # library option, e.g. opt1=1 (PAM_CONV_OPT_C96_STREAMED); reset after the capture
-            hip.lib.pam_conv_option(int(k[3:]), int(val)); opts.append(int(k[3:]))
-        elif k == 'b96_tile':                            # e.g. b96_tile=12x36
+        if k == 'b96_tile':                            # e.g. b96_tile=12x36
             hip.b96_tile = tuple(int(q) for q in val.split('x'))
-        elif k == 'stagger':                             # e.g. stagger=3:001/4:0012
-            hip.stagger = {int(a): tuple(int(c) for c in b) for a, b in (q.split(':') for q in val.split('/'))}
         else:
             cur = getattr(hip, k)
             if isinstance(cur, tuple):
@@ -40,17 +31,11 @@ for v in args.variants:
                 setattr(hip, k, val)
     x = net.input_buffer(args.n); x.copy_(torch.randn(x.shape, device=dev).to(x.dtype)); x[:, 3:] = 0
     hip.features(x); torch.cuda.synchronize()
-    if form == 'graph':
-        g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream(dev)
-        with torch.cuda.stream(s):
-            with torch.cuda.graph(g, stream=s):
-                out = hip.features(x)
-        runs.append((name, g.replay, net, (g, x, out)))          # keep the static input / output alive: the graph reads / writes them
-    else:
-        plan = hip.make_plan(x)
-        runs.append((name, (lambda p=plan, m=int(form[-1]): p.replay(m)), net, (plan, x)))
-    for o in opts:
-        hip.lib.pam_conv_option(o, 0)
+    g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            out = hip.features(x)
+    runs.append((name, g.replay, net, (g, x, out)))          # keep the static input / output alive: the graph reads / writes them
 for _, run, _, _ in runs:
     for _ in range(5): run()
 torch.cuda.synchronize()

@@ -12,10 +12,8 @@ ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--modes', default='graph')
 ap.add_argument('--backends', default='hip,miopen')
 ap.add_argument('--no-branch-streams', action='store_true')
-ap.add_argument('--lanes', default='0,1,2,3'); ap.add_argument('--order', default='0,1,2,3')
+ap.add_argument('--order', default='0,1,2,3')
 ap.add_argument('--config', default='', help='executor configuration (HipHRNet.CONFIGS); empty = the flags below'); ap.add_argument('--merge', type=int, default=2, help='0: no merged fuse convs, 1: strided chains only, 2: + up-convs')
-ap.add_argument('--fuse-blocks', type=int, default=1, help='1: fused, grouped BasicBlock kernel; 0: one launch per convolution')
-ap.add_argument('--fuse-max', type=int, default=0, help='0 = by batch size'); ap.add_argument('--fuse-waves', type=int, default=8); ap.add_argument('--group-fuse', type=int, default=0)
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 flops = hrnet.count_flops() * args.n
@@ -40,9 +38,8 @@ for backend in args.backends.split(','):
         net = hrnet.HRNetPose(48, 17, None, use_graph=(mode == 'graph'), backend=backend)
         if backend == 'hip':
             net.hip.multi_stream = not args.no_branch_streams
-            net.hip.lane_of = tuple(int(q) for q in args.lanes.split(',')); net.hip.order = tuple(int(q) for q in args.order.split(','))
+            net.hip.order = tuple(int(q) for q in args.order.split(','))
             net.hip.merge_fuse = args.merge >= 1; net.hip.merge_up = args.merge >= 2
-            net.hip.fuse_blocks = bool(args.fuse_blocks); net.hip.fuse_max_branches = args.fuse_max or None; net.hip.fuse_waves = args.fuse_waves; net.hip.group_fuse = bool(args.group_fuse)
             if args.config:
                 net.hip.apply_config(args.config)
         x = net.input_buffer(args.n)

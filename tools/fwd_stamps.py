@@ -20,8 +20,6 @@ for kv in [q for q in args.spec.split(',') if q]:
     k, _, val = kv.partition('=')
     if k == 'b96_tile':
         hip.b96_tile = tuple(int(q) for q in val.split('x')); continue
-    if k == 'stagger':                                   # e.g. stagger=3:001/4:0012
-        hip.stagger = {int(a): tuple(int(c) for c in b) for a, b in (q.split(':') for q in val.split('/'))}; continue
     cur = getattr(hip, k)
     setattr(hip, k, tuple(int(c) for c in val) if isinstance(cur, tuple) else (int(val) if cur is None else type(cur)(int(val))))
 x = net.input_buffer(args.n); x.copy_(torch.randn(x.shape, device=dev).to(x.dtype)); x[:, 3:] = 0

@@ -9,30 +9,26 @@ from pam import hrnet
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, default=20); ap.add_argument('--iters', type=int, default=30)
-ap.add_argument('--fuse-max', type=int, default=0); ap.add_argument('--mode', type=int, default=0); ap.add_argument('--dag', type=int, default=0); ap.add_argument('--no-branch-streams', action='store_true')
+ap.add_argument('--config', default=''); ap.add_argument('--no-branch-streams', action='store_true')
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 net = hrnet.HRNetPose(48, 17, None, use_graph=False, backend='hip')
 hip = net.hip
-hip.fuse_max_branches = args.fuse_max or None
+if args.config:
+    hip.apply_config(args.config)
 hip.multi_stream = not args.no_branch_streams
-hip.dag = bool(args.dag)
 x = net.input_buffer(args.n); x.copy_(torch.randn(x.shape, device=dev).to(x.dtype))
 prev = 0.0
 for stop in ('stem', 'layer1', 'stage2', 'stage3', None):
     hip.stop_after = stop
     hip.prof = None
     hip.features(x); torch.cuda.synchronize()
-    if hip.dag:                                      # the dependency-precise schedule only replays as a launch plan
-        plan = hip.make_plan(x)
-        run, info = (lambda: plan.replay(args.mode)), '%d launches, %d events' % (plan.launches, plan.events)
-    else:
-        g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream(dev)
-        with torch.cuda.stream(s):
-            with torch.cuda.graph(g, stream=s):
-                y = hip.features(x)
-        run, info = g.replay, 'captured hipGraph'
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream(dev)
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            y = hip.features(x)
+    run, info = g.replay, 'captured hipGraph'
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)

@@ -9,7 +9,7 @@ args = ap.parse_args()
 csrc = os.path.join(ROOT, 'part-aware_measurement_for_3d_pose_estimation_and_tracking_amd', 'csrc')
 so = '/tmp/libbb2_diag_%d.so' % os.getpid()
 subprocess.check_call(['hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-ffp-contract=off', '-DPAM_DIAG'] +
-                      ['-D' + d for d in args.defs.split(',') if d] + ['-shared', os.path.join(csrc, 'pam_block2.hip'), os.path.join(csrc, 'pam_plan.hip'), '-o', so])
+                      ['-D' + d for d in args.defs.split(',') if d] + ['-shared', os.path.join(csrc, 'pam_block2.hip'), '-o', so])
 import numpy as np, torch, torch.nn as nn
 import pam
 from pam import _lib, hrnet_hip
