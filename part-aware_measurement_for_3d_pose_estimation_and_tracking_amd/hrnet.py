@@ -267,7 +267,7 @@ class HRNetPose(object):
 
     def __init__(self, c, nof_joints, checkpoint_path, model_name='HRNet', resolution=(384, 288), hrpose_args=None,
                  device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16, backend='hip', graph_bucket=4,
-                 shard_crops=False, group=None, autotune=False):
+                 shard_crops=False, group=None, autotune=False, max_crops=32):
         assert model_name == 'HRNet' and int(nof_joints) == 17
         if not torch.cuda.is_available():
             raise RuntimeError('HRNetPose needs a GPU (the preprocessing / decode kernels are HIP only; no CPU fallback)')
@@ -325,6 +325,12 @@ class HRNetPose(object):
         # different configurations differ in the last bf16 bits, and a test that compares an eager forward with a replay needs both in ONE)
         self.autotune = bool(autotune) and backend == 'hip' and use_graph
         self.tuned = {}                                   # crop count -> {'choice': configuration name} of every replay captured so far
+        self._kp_pinned = {}         # crop count -> two pinned host buffers for predict()'s keypoints
+        # activations of the captured forwards: one arena per replay slot, sized for max_crops crops per forward (a larger forward gets a
+        # new, larger arena; the captures made before keep theirs) -- hrnet_hip.ActivationArena
+        self.max_crops = int(max_crops)
+        self._arenas = {}
+        self._arena_bytes_per_crop = None
         self._pools = {}             # graph memory pool per replay slot: graphs of ONE slot replay one after the other and may share
                                      # intermediates; the two slots of FramePipeline(pose_streams=2) replay concurrently and must not
         self.stream = torch.cuda.current_stream(self.device)
@@ -375,6 +381,7 @@ class HRNetPose(object):
         if g is None:
             if self.backend == 'hip':
                 self.hip.apply_config(self.config_for(n))
+                self.hip.arena = self._arena_for(n, slot)
             other = self._graphs.get((n, 'features' if kind == 'heatmaps' else 'heatmaps', slot))
             static_in = other[1] if other is not None else torch.empty_like(x)     # one input buffer per batch size and slot
             static_in.copy_(x)
@@ -388,6 +395,8 @@ class HRNetPose(object):
                 graph = _lib.new_graph()
                 with torch.cuda.graph(graph, pool=self._pool_of(slot)):
                     static_out = self._forward(static_in, kind)
+            if self.backend == 'hip':
+                self.hip.arena = None
             g = (graph, static_in, static_out)
             self._graphs[(n, kind, slot)] = g
         graph, static_in, static_out = g
@@ -396,18 +405,29 @@ class HRNetPose(object):
         graph.replay()
         return static_out
 
-    def _capture(self, static_in, kind, slot=0):
-        with torch.no_grad():
-            s = torch.cuda.Stream(self.device)
-            s.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    self._forward(static_in, kind)
-            torch.cuda.current_stream(self.device).wait_stream(s)
-            graph = _lib.new_graph()
-            with torch.cuda.graph(graph, pool=self._pool_of(slot)):
-                static_out = self._forward(static_in, kind)
-        return graph, static_in, static_out
+    def _arena_for(self, n, slot):
+        """The activation arena the n-crop capture of `slot` allocates from (created / replaced by a larger one on demand)."""
+        from .hrnet_hip import ActivationArena
+        if self._arena_bytes_per_crop is None:            # largest epoch of a one-crop forward, from a shape-only walk of this executor
+            hip, probe = self.hip, ActivationArena()
+            saved = (hip.multi_stream, hip.arena, hip.count, hip.prof)
+            hip.multi_stream, hip.arena, hip.count, hip.prof = False, probe, None, None
+            try:
+                H, W = self.resolution
+                hip._features(torch.empty((1, self.in_channels, H, W), dtype=self.dtype, device='meta').contiguous(memory_format=torch.channels_last))
+            finally:
+                hip.multi_stream, hip.arena, hip.count, hip.prof = saved
+            self._arena_bytes_per_crop = probe.peak       # per tensor rounded up to 256 B: n crops need <= n times this
+        ar = self._arenas.get(slot)
+        need = n * self._arena_bytes_per_crop
+        if ar is None or ar.half_bytes < need:
+            # first arena: max_crops crops.  A forward beyond that gets a new arena of TWICE its need (the captures made so far keep the
+            # old one: their kernels hold its addresses, and a captured graph is never destroyed, _lib.new_graph), so a crop count that
+            # creeps upwards costs at most 4 x the largest forward's need in total; a caller that knows its largest forward says so
+            # (max_crops: FramePipeline passes views x max_dets, predict() its batch_size) and gets exactly one arena
+            ar = ActivationArena(self.device, max(need, self.max_crops * self._arena_bytes_per_crop) if ar is None else 2 * need)
+            self._arenas[slot] = ar
+        return ar
 
     def _pool_of(self, slot):
         if slot not in self._pools:
@@ -495,6 +515,8 @@ class HRNetPose(object):
         ``ivclabpose.PersonTrack_Project3DPose`` can hand them to the frame kernel without a host round trip when the caller
         passes the dump on unchanged."""
         V = len(person_bbox_list)
+        if not self._arenas:
+            self.max_crops = max(self.max_crops, int(batch_size))
         views, slots, boxes, frames, cnt = [], [], [], {}, [0] * V
         for v, persons in enumerate(person_bbox_list):
             for p in persons:
@@ -548,37 +570,105 @@ class HRNetPose(object):
             kp = gather_crop_keypoints(kp[lo:hi].contiguous(), n, self.world, self.rank, self.group)
             # the tracker's device-side input, rebuilt from the gathered rows: (view, slot) <- (y, x, score) as float64
             det[view_of.long(), slot_of.long()] = kp[:, :, [1, 0, 2]].double()
-        kp_h = kp.cpu().numpy().astype(np.float64)       # the reference's contract is host lists: one device -> host copy per call
-        flat = kp_h.reshape(n, 51).tolist()
-        score = kp_h[:, :, 2].tolist()
-        for i in range(n):
-            out[views[i]].append(dict(bbox=list(boxes[i]), keypoints=flat[i], keypoints_score=score[i], feature=[]))
-        yxs = kp_h[:, :, [1, 0, 2]]
-        first = np.concatenate([[0], np.cumsum(cnt)])
-        out.attach(det, n_det, [yxs[first[v]:first[v + 1]] for v in range(V)])
+        # The reference's contract is host lists -- but nothing needs them before the caller looks: the device -> host copy of the keypoints
+        # is only ENQUEUED here (pinned buffer, this stream) and the per-person dicts are built at the first access of the dump
+        # (DumpResults).  A loop that passes the dump straight on to PersonTrack_Project3DPose waits for the GPU once per frame (behind
+        # the tracker kernel) instead of twice, and the tracker kernel is queued right behind the decode instead of after a host round trip.
+        host = self._pinned_kp(n)
+        host.copy_(kp, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        out.attach_pending(det, n_det, host, done, views, boxes, cnt)
+        import weakref
+        self._kp_last[1] = weakref.ref(out)
         return out
+
+    def _pinned_kp(self, n):
+        """A pinned (n, 17, 3) float32 host buffer for the keypoints of one call; two per crop count, used alternately (a dump that is
+        still pending when its buffer comes round again is materialised first)."""
+        ring = self._kp_pinned.setdefault(n, [])
+        if len(ring) < 2:
+            ring.append([torch.empty((n, 17, 3), dtype=torch.float32).pin_memory(), None])
+            ent = ring[-1]
+        else:
+            ent = ring[0]; ring.reverse()
+            prev = ent[1]() if ent[1] is not None else None
+            if prev is not None:
+                prev._materialise()
+        self._kp_last = ent
+        return ent[0]
 
 
 class DumpResults(list):
-    """``dump_results`` of the reference (list per view of person dicts) + the same keypoints still on the device."""
+    """``dump_results`` of the reference (list per view of person dicts) + the same keypoints still on the device.
+
+    The per-person dicts are built LAZILY: ``predict`` only enqueues the device -> host copy of the keypoints; the first access to the
+    list's content (indexing, iteration, comparison, printing, copying, pickling ...) waits for that copy and fills the per-view lists
+    in place.  Until then nobody can have edited the dicts, so the device copy is trivially the truth."""
     device_det = None        # (views, max_dets, 17, 3) float64 rows (y, x, score) at (view, slot)
     device_n_det = None      # (views,) int32
-    poses_host = None        # per view (n, 17, 3) float64 (y, x, score): what ivclabpose._unpack would rebuild from the dicts
+    _poses_host = None       # per view (n, 17, 3) float64 (y, x, score): what ivclabpose._unpack would rebuild from the dicts
+    _pending = None          # (pinned host keypoints, event, views, boxes, per-view counts) until the first access
+    _witness = None
 
     def attach(self, det, n_det, poses_host):
-        self.device_det, self.device_n_det, self.poses_host = det, n_det, poses_host
+        self.device_det, self.device_n_det, self._poses_host = det, n_det, poses_host
+        self._seal()
+
+    def attach_pending(self, det, n_det, host_kp, event, views, boxes, cnt):
+        self.device_det, self.device_n_det = det, n_det
+        self._pending = (host_kp, event, views, boxes, cnt)
+
+    def _seal(self):
         # complete witness of what the tracker would read from the dicts (ivclabpose._unpack: 'keypoints' AND 'keypoints_score'):
         # object identities + a hash of all 51 + 17 numbers per person -- an interior edit or a re-scored joint invalidates it
         self._witness = [[(id(it), id(it['keypoints']), id(it['keypoints_score']),
-                           hash(tuple(it['keypoints'])), hash(tuple(it['keypoints_score']))) for it in items] for items in self]
+                           hash(tuple(it['keypoints'])), hash(tuple(it['keypoints_score']))) for it in items] for items in list.__iter__(self)]
+
+    def _host_rows(self):
+        """(n, 17, 3) float64 (x, y, score) rows of the call, waiting for the copy predict() enqueued."""
+        host_kp, event = self._pending[0], self._pending[1]
+        event.synchronize()
+        return host_kp.numpy().astype(np.float64)
+
+    @property
+    def poses_host(self):
+        if self._poses_host is None and self._pending is not None:
+            kp_h, cnt = self._host_rows(), self._pending[4]
+            yxs = kp_h[:, :, [1, 0, 2]]
+            first = np.concatenate([[0], np.cumsum(cnt)])
+            self._poses_host = [yxs[first[v]:first[v + 1]] for v in range(len(cnt))]
+        return self._poses_host
+
+    @poses_host.setter
+    def poses_host(self, value):
+        self._poses_host = value
+
+    def _materialise(self):
+        if self._pending is None:
+            return
+        kp_h = self._host_rows()
+        _, _, views, boxes, cnt = self._pending
+        _ = self.poses_host
+        self._pending = None
+        n = len(views)
+        flat = kp_h.reshape(n, 51).tolist()
+        score = kp_h[:, :, 2].tolist()
+        for i in range(n):
+            list.__getitem__(self, views[i]).append(dict(bbox=list(boxes[i]), keypoints=flat[i], keypoints_score=score[i], feature=[]))
+        self._seal()
 
     def device_valid(self):
-        """True while the dicts are exactly what predict() returned: same objects and every keypoint / keypoints_score value
-        untouched (the tracker reads both, /root/reference/src/ivclabpose.py:236-244).  Any edit -- masking or re-scoring joints
-        between PersonPoseDetect and PersonTrack_Project3DPose -- sends the call through the host dicts again."""
-        if self.device_det is None or len(self._witness) != len(self):
+        """True while the dicts are exactly what predict() returned: never looked at yet, or same objects and every keypoint /
+        keypoints_score value untouched (the tracker reads both, /root/reference/src/ivclabpose.py:236-244).  Any edit -- masking or
+        re-scoring joints between PersonPoseDetect and PersonTrack_Project3DPose -- sends the call through the host dicts again."""
+        if self.device_det is None:
             return False
-        for items, wit in zip(self, self._witness):
+        if self._pending is not None:
+            return True
+        if self._witness is None or len(self._witness) != list.__len__(self):
+            return False
+        for items, wit in zip(list.__iter__(self), self._witness):
             if len(items) != len(wit):
                 return False
             for it, (a, b, c, hk, hs) in zip(items, wit):
@@ -588,6 +678,25 @@ class DumpResults(list):
                 if hash(tuple(k)) != hk or hash(tuple(sc)) != hs:
                     return False
         return True
+
+
+def _lazy(name):
+    base = getattr(list, name)
+
+    def method(self, *a, **k):
+        self._materialise()
+        return base(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+# every way Python code (and the C helpers that go through the iterator protocol for list SUBCLASSES: list(), json, pickle, copy)
+# can see the content first fills it in; __len__ is the number of views and needs no data
+for _n in ('__getitem__', '__iter__', '__reversed__', '__contains__', '__eq__', '__ne__', '__lt__', '__le__', '__gt__', '__ge__', '__repr__',
+           '__add__', '__iadd__', '__mul__', '__imul__', '__rmul__', '__setitem__', '__delitem__', '__reduce_ex__', 'append', 'extend',
+           'insert', 'pop', 'remove', 'index', 'count', 'copy', 'sort', 'reverse', 'clear'):
+    setattr(DumpResults, _n, _lazy(_n))
+del _n
 
 
 def measure_bf16_drift(net, n_crops=2, seed=2, checker_device='cpu'):

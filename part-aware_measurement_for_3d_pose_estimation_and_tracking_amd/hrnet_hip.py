@@ -204,6 +204,37 @@ class PackedPointwise64(object):
         self.b = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(64)).to(device).contiguous()
 
 
+class ActivationArena(object):
+    """Activations of the captured forwards of ONE replay slot: a bump allocator over one device buffer of two halves.  The executor
+    calls ``epoch()`` at the start of the stem, of layer1's successor and of every HR module; an epoch allocates from the half the
+    epoch before last used -- everything produced two epochs ago is dead by then (a module's tensors are read by that module and by the
+    next one's first kernels only, and a full join of the branch streams lies between any two epochs).  Every capture of the slot (one
+    per crop-count bucket) replays into the same buffer: they run one after the other, never at the same time.  Round 3 let every
+    capture keep its own tensors: 197 GiB after a sweep over the 55 crop-count buckets of the Panoptic workload (tools/graph_memory.py).
+    Without a device (``half_bytes`` None) the arena only measures: the largest epoch of a shape-only walk sizes the real one."""
+
+    def __init__(self, device=None, half_bytes=None):
+        self.half_bytes = half_bytes
+        self.buf = torch.empty(2 * half_bytes, dtype=torch.uint8, device=device) if half_bytes else None
+        self.half, self.off, self.peak = 1, 0, 0
+
+    def epoch(self):
+        self.half ^= 1
+        self.off = 0
+
+    def count(self, nbytes):
+        self.off += (nbytes + 255) // 256 * 256
+        self.peak = max(self.peak, self.off)
+
+    def alloc(self, n, c, h, w):
+        nbytes = 2 * n * c * h * w
+        a = self.half * self.half_bytes + self.off
+        self.count(nbytes)
+        if self.off > self.half_bytes:
+            raise _lib.PamError('activation arena too small: epoch needs > %d bytes' % self.half_bytes)
+        return self.buf[a:a + nbytes].view(torch.bfloat16).as_strided((n, c, h, w), (h * w * c, 1, w * c, c))
+
+
 class ConvEngine(object):
     """Kernel launchers shared by the pose network (HipHRNet) and the person detector (yolov3.HipDarknet)."""
     count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
@@ -213,6 +244,20 @@ class ConvEngine(object):
     def _prof_add(self, x, family, sig, nbytes, flops, fn):
         if self.prof is not None and x.device.type == 'cuda':
             self.prof.append(dict(family=family, sig=(family,) + tuple(sig), bytes=nbytes, flops=flops, fn=fn))
+    arena = None                # an ActivationArena: outputs are carved from it instead of torch.empty (HRNetPose's captured replays)
+
+    def _new(self, n, c, h, w, device):
+        """A fresh (n, c, h, w) channels-last bf16 activation: from the arena when one is set, else from the caching allocator (kept
+        alive until the forward has been issued: another stream may still read what a freed block held)."""
+        if self.arena is not None and device.type != 'meta':
+            return self.arena.alloc(n, c, h, w)
+        if self.arena is not None:
+            self.arena.count(2 * n * c * h * w)
+        y = torch.empty((n, c, h, w), dtype=torch.bfloat16, device=device, memory_format=torch.channels_last)
+        if self._keep is not None:
+            self._keep.append(y)
+        return y
+
     tile_cfg = -1
     c96_slab = 0                # 96 -> 96 3x3 layers: 0 = k_conv3x3, 48 / 96 = the streamed kernel with slabs of that many output channels
     _keep = None
@@ -226,9 +271,7 @@ class ConvEngine(object):
         assert cin == op.cin and (x.device.type == 'meta' or (x.stride(1) == 1 and x.stride(2) == w * in_cs and x.stride(0) == h * w * in_cs)), (x.shape, op.cin)
         ho = (h + 2 * op.pad - op.kh) // op.stride + 1
         wo = (w + 2 * op.pad - op.kw) // op.stride + 1
-        y = torch.empty((n, op.cout, ho, wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-        if self._keep is not None:
-            self._keep.append(y)
+        y = self._new(n, op.cout, ho, wo, x.device)
         if self.count is not None:       # unique bytes this conv must move: input + weights + bias [+ residual] + output
             self.count['bytes'] += 2 * (x.numel() + y.numel() + op.cout * op.kh * op.kw * op.cin + (y.numel() if res is not None else 0)) + 4 * op.cout
             self.count['flops'] += 2 * y.numel() * op.kh * op.kw * op.cin
@@ -270,9 +313,7 @@ class ConvEngine(object):
         """One BasicBlock (PackedBlock with ``wpack``: C = 48) on x through the resident-weights kernel; tile = (rows, cols) or None."""
         n, c, h, w = x.shape
         assert c == op.c, (x.shape, op.c)
-        y = torch.empty_like(x)
-        if self._keep is not None:
-            self._keep.append(y)
+        y = self._new(n, c, h, w, x.device)
         nbytes, flops = 2 * (2 * x.numel() + 2 * 9 * c * c) + 8 * c, 2 * 2 * x.numel() * 9 * c
         if self.count is not None:
             self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
@@ -303,9 +344,7 @@ class ConvEngine(object):
         """ReLU(conv1x1 64 -> 64 (x)) as a pure stream (k_pw1)."""
         n, c, h, w = x.shape
         assert c == 64
-        y = torch.empty_like(x)
-        if self._keep is not None:
-            self._keep.append(y)
+        y = self._new(n, c, h, w, x.device)
         nbytes, flops = 2 * (2 * x.numel() + 64 * 64) + 4 * 64, 2 * n * h * w * 64 * 64
         if self.count is not None:
             self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
@@ -324,12 +363,8 @@ class ConvEngine(object):
         """X = ReLU(conv3(y2) [+ downsample(x0)] [+ res]); y1 = ReLU(conv1_next(X)) in one launch -> (X, y1 or None)."""
         n, c, h, w = y2.shape
         assert c == 64 and (x0 is None) == (op.S == 1), (y2.shape, op.S)
-        X = torch.empty((n, 256, h, w), dtype=torch.bfloat16, device=y2.device, memory_format=torch.channels_last)
-        Y = torch.empty((n, 64, h, w), dtype=torch.bfloat16, device=y2.device, memory_format=torch.channels_last) if op.w1 is not None else None
-        if self._keep is not None:
-            self._keep.append(X)
-            if Y is not None:
-                self._keep.append(Y)
+        X = self._new(n, 256, h, w, y2.device)
+        Y = self._new(n, 64, h, w, y2.device) if op.w1 is not None else None
         M = n * h * w
         nbytes = 2 * (y2.numel() + (x0.numel() if x0 is not None else 0) + (res.numel() if res is not None else 0) + X.numel() +
                       (Y.numel() if Y is not None else 0) + op.S * 256 * 64 + (64 * 256 if op.w1 is not None else 0)) + 4 * (256 + (64 if op.w1 is not None else 0))
@@ -354,9 +389,7 @@ class ConvEngine(object):
 
     def upsample_add(self, base, terms, shifts, relu):
         n, c, h, w = base.shape
-        y = torch.empty_like(base)
-        if self._keep is not None:
-            self._keep.append(y)
+        y = self._new(n, c, h, w, base.device)
         if self.count is not None:
             self.count['bytes'] += 2 * (2 * base.numel() + sum(t.numel() for t in terms))
             self.count['launches'] += 1
@@ -380,9 +413,7 @@ class ConvEngine(object):
         n, ca, h2, w2 = a.shape
         _, cb, h, w = b.shape
         assert h == 2 * h2 and w == 2 * w2 and b.shape[0] == n, (a.shape, b.shape)
-        y = torch.empty((n, ca + cb, h, w), dtype=torch.bfloat16, device=a.device, memory_format=torch.channels_last)
-        if self._keep is not None:
-            self._keep.append(y)
+        y = self._new(n, ca + cb, h, w, a.device)
         if self.count is not None:
             self.count['bytes'] += 2 * (a.numel() + b.numel() + y.numel())
             self.count['launches'] += 1
@@ -539,6 +570,7 @@ class HipHRNet(ConvEngine):
     def _hr_module(self, mod, xs):
         """xs[b]: tensor, or ('lazy', transition op, source tensor) for a branch this stage creates.
         Stream b runs branch b's blocks and the fuse chains that hang off its output; ONE join; sum i on stream i."""
+        self._epoch()
         xs = list(xs)
         fuse = mod['fuse']
         terms = [dict() for _ in fuse]
@@ -601,7 +633,12 @@ class HipHRNet(ConvEngine):
                 cur.wait_stream(st)
         return xs[0]
 
+    def _epoch(self):
+        if self.arena is not None:
+            self.arena.epoch()
+
     def _features(self, x8):
+        self._epoch()
         x = self.conv(self.conv1, x8, relu=True)
         x = self.conv(self.conv2, x, relu=True)
         if self.stop_after == 'stem':

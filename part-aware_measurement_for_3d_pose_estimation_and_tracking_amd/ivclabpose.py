@@ -183,8 +183,9 @@ class ivclabpose(object):
         if dev is not None and dev.shape[1] == self.tracker.max_dets and dev.shape[0] == len(self.cameras) and dump_results.device_valid():
             # the dump is the one PersonPoseDetect returned, untouched: its keypoints are still on the device in the tracker's
             # layout -> no re-packing, no host -> device copy (the dicts stay the source of truth whenever the caller edits them)
-            poses = dump_results.poses_host
+            # (the frame kernel is queued first: the one host wait of this call, behind it, also covers the keypoints' copy predict() enqueued)
             asso_time, update_time, init_time = self.tracker.tracking_dev(frame_id, self.cameras, dump_results.device_n_det, dev, build3D)
+            poses = dump_results.poses_host
         else:
             poses = self._unpack(dump_results)
             boxes = [np.array([it['bbox'] for it in items]) for items in dump_results]

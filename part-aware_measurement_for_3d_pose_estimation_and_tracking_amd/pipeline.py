@@ -42,7 +42,8 @@ class FramePipeline(object):
                                 np.stack([c.RK_INV for c in calib_cameras]), np.stack([c.position for c in calib_cameras]))
         # net: an existing HRNetPose to share (weights, packed images, captured graphs) between several pipelines of one process
         self.net = net if net is not None else (HRNetPose(48, 17, None, resolution=(384, 288), device=device, use_graph=use_graph, seed=seed,
-                                                          max_dets=max_dets, autotune=autotune) if hrnet else None)
+                                                          max_dets=max_dets, autotune=autotune,
+                                                          max_crops=len(calib_cameras) * max_dets) if hrnet else None)
         self.shard = shard
         # exchange: 'torch' = torch.distributed (RCCL when the backend is nccl, gloo in the CPU tests); 'abi' = pam_allgather_keypoints,
         # the library's own RCCL call on the decode stream (view sharding only)
