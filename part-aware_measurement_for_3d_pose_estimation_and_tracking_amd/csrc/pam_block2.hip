@@ -300,8 +300,9 @@ __global__ __launch_bounds__(512) void k_bblock2_48(BB2Args a) {
 //   * K = (chunk, tap) -- chunk-major, 27 k-steps of 32 per convolution: conv1 starts when the FIRST 32-channel chunk of X has landed.
 //   * all eight waves multiply (5 x 6 accumulator tiles for conv1, 4 x 6 for conv2: 11 / 10 fragment reads per 30 / 24 MFMAs); waves 0-3
 //     also feed the ring (3 DMA pieces each per two k-steps), waves 4-7 fetch X (all three chunks up front, 30 pieces each, counted vmcnt).
-//   * one raw s_barrier per TWO k-steps (top of every odd k-step s = 2p + 1): everybody is done reading k-steps <= s, so the pair
-//     (2p, 2p + 1) is refilled with (2p + 6, 2p + 7); the pair (2p + 2, 2p + 3) has landed (vmcnt(3): only the youngest pair is in flight).
+//   * one raw s_barrier per KPB k-steps (KPB = 2, or 4 where the X tile leaves room for a 12-slot ring): at the top of the last k-step of
+//     group p everybody is done reading the group, so its slots are refilled with group p + 3; group p + 1 has landed (counted vmcnt: only
+//     the youngest group is in flight).  Half-size items spend a third of their K loops at these barriers with KPB = 2.
 //   * the weight fragments are single-buffered: the MFMAs of a k-step run N tile by N tile and fragment j of the next k-step is read right
 //     behind the 5 MFMAs that used fragment j of this one; the pixel fragments are double-buffered.  (Register plan: 120 accumulators +
 //     24 + 40 fragment registers; pinning the issue order with sched_group_barrier made hipcc spill 114 registers, plain program order
@@ -311,7 +312,6 @@ __global__ __launch_bounds__(512) void k_bblock2_48(BB2Args a) {
 constexpr int B96_NW = 8;                  // waves per workgroup (two per SIMD)
 constexpr int B96_NS = 27;                 // k-steps per convolution
 constexpr int B96_KIMG = 96 * 64;          // one k-step's weight image
-constexpr int B96_RING = 6;                // ring slots
 // M tiles per wave (conv1, conv2) are template parameters: <5, 4> takes items of up to 12 x 36 positions, <3, 2> half-size items
 constexpr int B96_TST = B96_NW * 16 * 64;  // byte distance between a wave's consecutive M tiles inside a chunk image (tile = wave + 4 i)
 constexpr int B96_NPW = 10;                // X pieces (16 slots x 64 B) per chunk and loader wave (waves 4-7): XSP <= 640 slots
@@ -329,8 +329,10 @@ __device__ __attribute__((aligned(256))) const uint32_t g_bb96_zero[64] = {0};
 
 #define B96_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int MT1, int MT2>
+// KPB = k-steps per ring barrier (2 or 4); the ring has 3 * KPB slots: the group being read, the one that has landed, the one in flight
+template <int MT1, int MT2, int KPB>
 __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
+    constexpr int RING = 3 * KPB, NG = (2 * B96_NS + KPB - 1) / KPB;     // ring slots; groups of KPB k-steps in the 54-step weight stream
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -354,12 +356,13 @@ __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
 
     // ---- DMA roles -------------------------------------------------------------------------------------------------------------------
     const char* wsrc = a.wpack + lane * 16;
-    auto wdma_pair = [&](int q) {                        // k-steps 2q, 2q + 1 of the 54-step stream -> ring slots (2q % 6, + 1): waves 0-3, 3 pieces each
+    auto wdma_group = [&](int q) {                       // k-steps KPB q .. KPB q + KPB - 1 of the weight stream -> ring slots (KPB q) % RING ..: waves 0-3, 1.5 KPB pieces each
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int e = wave + 4 * k;
-            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + 1024 + (size_t)(2 * q) * B96_KIMG + e * 1024),
-                                             (lds_void*)(ring + ((2 * q) % B96_RING) * B96_KIMG + e * 1024), 16, 0, 0);
+        for (int k = 0; k < 3 * KPB / 2; ++k) {
+            const int e = wave + 4 * k;                  // piece of the group (6 per k-step)
+            if (KPB * q + e / 6 < 2 * B96_NS)            // the last group of the stream may be short
+                __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + 1024 + (size_t)(KPB * q) * B96_KIMG + e * 1024),
+                                                 (lds_void*)(ring + ((KPB * q) % RING) * B96_KIMG + e * 1024), 16, 0, 0);
         }
     };
     // X, chunk-major: piece P of a chunk image = slots 16 P .. 16 P + 15, lane -> slot 16 P + (lane >> 2), physical piece lane & 3 holding
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
     };
     if (wave < 4) {
         if (wave == 0) __builtin_amdgcn_global_load_lds((glb_void*)wsrc, (lds_void*)Bs, 16, 0, 0);     // bias
-        wdma_pair(0); wdma_pair(1); wdma_pair(2);
+        wdma_group(0); wdma_group(1); wdma_group(2);
     } else {
         const char* img = (const char*)a.in + (size_t)n * a.H * a.W * 192;
 #pragma unroll
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
     const float* bias = (const float*)Bs;
 
     B96_STAMP(1);
-    if (wave < 4) B96_VM(6); else B96_VM(0);             // pair 0 of the ring (and the bias) / chunk 0 of X have landed ...
+    if (wave < 4) B96_VM(3 * KPB); else B96_VM(0);       // group 0 of the ring (and the bias) / chunk 0 of X have landed ...
     asm volatile("s_barrier" ::: "memory");              // ... everybody's
     if (wave >= 4) { xdma_chunk(1); xdma_chunk(2); }
     B96_STAMP(2);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
     auto conv = [&](auto MTC, auto S0C) {
         constexpr int MT = decltype(MTC)::value, S0 = decltype(S0C)::value;
         bf16x8 af[6], bf[2][MT];
-        auto wrow = [&](int s, int j) { return *(const bf16x8*)(wl + (s % B96_RING) * B96_KIMG + j * 1024); };
+        auto wrow = [&](int s, int j) { return *(const bf16x8*)(wl + (s % RING) * B96_KIMG + j * 1024); };
         auto xfrag = [&](int s, int i) {
             const int st = s - S0, c = st / 9, t = st - 9 * c;
             return *(const bf16x8*)(Xb + c * CS + aoff[t] + i * B96_TST);
@@ -429,14 +432,16 @@ __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
         for (int st = 0; st < B96_NS; ++st) {
             const int s = S0 + st, cur = st & 1, nxt = cur ^ 1;
             const bool more = st + 1 < B96_NS;
-            if (s & 1) {                                 // top of an odd k-step: the ring's barrier p = (s - 1) / 2
-                const int p = (s - 1) >> 1;
+            if (s % KPB == KPB - 1) {                    // top of the last k-step of group p: the ring's barrier
+                const int p = s / KPB;
                 __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's reads of k-step s (the youngest it has issued) are done
-                if (wave < 4) { if (p + 2 < B96_NS) B96_VM(3); else B96_VM(0); }     // pair p + 1 has landed; only pair p + 2 may still fly
-                else if (S0 == 0 && p == 3) B96_VM(B96_NPW);                        // chunk 1 of X: first read in k-step 8 (for k-step 9)
-                else if (S0 == 0 && p == 8) B96_VM(0);                              // chunk 2
+                // everybody is done reading group p -> it is refilled with group p + 3; group p + 1 has landed, only group p + 2 may still fly
+                if (wave < 4) { if (p + 2 < NG - 1) B96_VM(3 * KPB / 2); else B96_VM(0); }
+                // chunk c of X is first read in k-step 9 c - 1 (fragments of k-step 9 c): waited for at the last barrier at or before that
+                else if (S0 == 0 && s <= 8 && s + KPB > 8) B96_VM(B96_NPW);
+                else if (S0 == 0 && s <= 17 && s + KPB > 17) B96_VM(0);
                 asm volatile("s_barrier" ::: "memory");
-                if (wave < 4 && p + 3 < B96_NS) wdma_pair(p + 3);
+                if (wave < 4 && p + 3 < NG) wdma_group(p + 3);
             }
             constexpr int BPG = (MT + 5) / 6;            // pixel-fragment reads of the next k-step per N-tile group
 #pragma unroll
@@ -626,16 +631,20 @@ static int launch_bb96(void* stream, const void* in, const void* wpack, void* ou
     a.nitems = N * a.tiles_y * a.tiles_x;
     a.inv_pwx = 1.0f / (float)(a.TC + 4); a.inv_pwi = 1.0f / (float)(a.TC + 2);
     // junk M tiles of conv1 read up to 2 rows + 2 slots past the last real slot of a chunk image: keep that inside the allocation
-    size_t lds = (size_t)3 * a.xsp * 64 + 1024 + (size_t)B96_RING * B96_KIMG;
+    // half-size items with room for it: a 12-slot ring and one barrier per four k-steps
+    const int kpb = (inst == 0 && (size_t)3 * a.xsp * 64 + 1024 + (size_t)12 * B96_KIMG <= 160 * 1024) ? 4 : 2;
+    size_t lds = (size_t)3 * a.xsp * 64 + 1024 + (size_t)3 * kpb * B96_KIMG;
     const size_t reach = (size_t)2 * a.xsp * 64 + (size_t)(16 * B96_NW * kB96Inst[inst][0] + 2 * (a.TC + 4) + 3) * 64;
     if (reach > lds) lds = reach;
     if (lds > 160 * 1024) return PAM_E_ARG;
-    if (!pam_max_dynamic_lds((const void*)k_bblock2_96<5, 4>, 160 * 1024) || !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2>, 160 * 1024)) return PAM_E_HIP;
+    if (!pam_max_dynamic_lds((const void*)k_bblock2_96<5, 4, 2>, 160 * 1024) || !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 2>, 160 * 1024) ||
+        !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 4>, 160 * 1024)) return PAM_E_HIP;
 #ifdef PAM_DIAG
     a.stamps = g_bb2_stamps;
 #endif
-    if (inst == 0) pam_launch(k_bblock2_96<3, 2>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
-    else pam_launch(k_bblock2_96<5, 4>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    if (inst == 0 && kpb == 4) pam_launch(k_bblock2_96<3, 2, 4>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    else if (inst == 0) pam_launch(k_bblock2_96<3, 2, 2>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    else pam_launch(k_bblock2_96<5, 4, 2>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 

@@ -726,14 +726,52 @@ def measure_bf16_drift(net, n_crops=2, seed=2, checker_device='cpu'):
         else:
             h32 = ref(xb.float())
         hb = net.heatmaps(x8).float()
-    w = h32.shape[3]
-    a32, ab = h32.flatten(2).argmax(2), hb.flatten(2).argmax(2)
-    moved = (a32 != ab)
+    return drift_statistics(h32, hb, dict(crops=n_crops, weights=net.weights,
+                                          checker='same folded weights as a plain fp32 PyTorch module on the %s' % cdev.type))
+
+
+def drift_statistics(h32, hb, extra=None, planted_seed=5):
+    """What the bf16 stack's error does to the DECODE, in terms that bound something (random weights give nearly flat heat-maps whose
+    arg-max moves at the slightest error -- that rate alone says nothing about the kernels):
+      * ``rms_err``: RMS of (bf16 heat-map - fp32 heat-map) over all cells;
+      * decided joints: maps whose fp32 peak stands above every cell OUTSIDE its 3 x 3 neighbourhood by a margin > k x rms_err; on those the
+        bf16 arg-max should stay within one cell.  ``decided[k]`` = {frac, joints, max_cells} for k = 4, 8 (k = 8 is asserted in
+        tests/test_gpu_image.py: moving such a peak takes two cells whose errors differ by 8 sigma);
+      * planted peaks: one cell per map (seeded position) raised k x rms_err above the map's maximum in BOTH heat-maps, i.e. a joint the
+        network is sure about by k error sigmas: ``planted_peak_max_cells[k]`` = largest distance in cells between the two decodes, k = 4,
+        8, 16 (0 expected from k = 8; k = 16 asserted);
+      * the unconditioned rate (``argmax_moved_frac``) stays for the record."""
+    n, j, h, w = h32.shape
+    f32, fb = h32.flatten(2), hb.flatten(2)
+    a32, ab = f32.argmax(2), fb.argmax(2)
+    moved = a32 != ab
     cells = torch.maximum((a32 // w - ab // w).abs(), (a32 % w - ab % w).abs())
-    return dict(crops=n_crops, rel_l2_err=float((hb - h32).norm() / h32.norm()), argmax_moved_frac=float(moved.float().mean()),
-                argmax_max_cells=int(cells.max()), argmax_mean_cells_when_moved=float(cells[moved].float().mean()) if bool(moved.any()) else 0.0,
-                score_max_abs_err=float((hb.flatten(2).max(2)[0] - h32.flatten(2).max(2)[0]).abs().max()),
-                weights=net.weights, checker='same folded weights as a plain fp32 PyTorch module on the %s' % cdev.type)
+    rms = float((hb - h32).pow(2).mean().sqrt())
+    # margin of the fp32 peak over the rest of the map (3 x 3 neighbourhood of the peak excluded)
+    yy = torch.arange(h, device=h32.device).view(1, 1, h, 1); xx = torch.arange(w, device=h32.device).view(1, 1, 1, w)
+    py, px = (a32 // w).view(n, j, 1, 1), (a32 % w).view(n, j, 1, 1)
+    near = ((yy - py).abs() <= 1) & ((xx - px).abs() <= 1)
+    rest = h32.masked_fill(near, float('-inf')).flatten(2).max(2)[0]
+    margin = f32.max(2)[0] - rest
+    decided = {}
+    for k in (4, 8):
+        d = margin > k * rms
+        decided[str(k)] = dict(frac=float(d.float().mean()), joints=int(d.sum()), max_cells=int(cells[d].max()) if bool(d.any()) else 0)
+    planted = {}
+    g = torch.Generator().manual_seed(planted_seed)
+    pos = (torch.randint(0, h, (n, j), generator=g) * w + torch.randint(0, w, (n, j), generator=g)).to(h32.device).view(n, j, 1)
+    top = f32.max(2, keepdim=True)[0]
+    for k in (4, 8, 16):
+        amp = (top - torch.gather(f32, 2, pos)) + k * rms              # the planted cell ends k x rms above the map's own maximum
+        p32, pb = f32.scatter_add(2, pos, amp).argmax(2), fb.scatter_add(2, pos, amp).argmax(2)
+        planted[str(k)] = int(torch.maximum((p32 // w - pb // w).abs(), (p32 % w - pb % w).abs()).max())
+    out = dict(rel_l2_err=float((hb - h32).norm() / h32.norm()), rms_err=rms, decided=decided, planted_peak_max_cells=planted,
+               argmax_moved_frac=float(moved.float().mean()), argmax_max_cells=int(cells.max()),
+               argmax_mean_cells_when_moved=float(cells[moved].float().mean()) if bool(moved.any()) else 0.0,
+               score_max_abs_err=float((fb.max(2)[0] - f32.max(2)[0]).abs().max()),
+               headline='decided joints (fp32 peak margin > k x rms error) move by decided[k].max_cells; planted peaks of k x rms by planted_peak_max_cells[k]')
+    out.update(extra or {})
+    return out
 
 
 def smoke_check():

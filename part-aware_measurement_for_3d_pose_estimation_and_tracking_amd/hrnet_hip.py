@@ -438,7 +438,9 @@ class HipHRNet(ConvEngine):
         self._pack(folded_model, device)
         self.tile_cfg = -1
         # concurrency: the 2-4 branches of an HR module run on side streams (the coarse branches do not fill the chip)
-        self.side = [torch.cuda.Stream(device) for _ in range(3)]     # equal priorities: mixing them costs 1.5-2x (measured)
+        # equal priorities: a high-priority stream for the deep branches (whose short kernels wait for CUs behind the fused blocks' long items)
+        # doubles the forward -- round 4: 4.2-4.6 ms vs 2.31 ms with side streams 2 / 2 + 3 at priority -1; all three: 2.65 ms
+        self.side = [torch.cuda.Stream(device) for _ in range(3)]
         self.multi_stream = True
         self.count = None            # set to a dict to tally algorithmic bytes / flops of one forward (bench.py)
 

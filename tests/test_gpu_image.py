@@ -92,6 +92,12 @@ def test_bf16_stack_vs_fp32(net):
     assert abs(d['rel_l2_err'] - rel) < 1e-6
     assert d['rel_l2_err'] < 0.03 and d['score_max_abs_err'] < 0.05 * float(h32.flatten(2).max(2)[0].abs().max())
     assert d['argmax_moved_frac'] <= max(2.0 * drift_mi, 0.15), (d, drift_mi)     # random weights: near-flat maps move easily
+    # the figures that bound something: a joint whose fp32 peak stands > 8 error sigmas above the rest of its map stays within one cell,
+    # and a planted peak of 16 error sigmas (the same cell raised in both heat-maps) decodes to the same cell
+    assert d['decided']['8']['max_cells'] <= 1, d
+    assert d['planted_peak_max_cells']['16'] == 0, d
+    dm = hrnet.drift_statistics(h32, hm.float())                                  # PyTorch-ROCm's own bf16 convolutions: the same order of error
+    assert dm['decided']['8']['max_cells'] <= 1 and d['rms_err'] <= 2.0 * dm['rms_err'] + 1e-4, (dm, d)
 
 
 def test_hipgraph_replay_matches_eager():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Resident-weights BasicBlock (k_bblock2, C = 48) vs the ring kernel (k_bblock) and the two-launch path (development tool)."""
+"""Fused BasicBlock kernels (k_bblock2_48 / k_bblock2_96) vs the two-launch path, over crop counts and item tiles (development tool)."""
 import os, sys, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn as nn
@@ -43,9 +43,8 @@ for n in args.n:
     x = torch.randn((n, c, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
     fl = 2 * 2.0 * n * h * w * c * c * 9
     e.c96_slab = 48
-    tr = timeit(lambda: e.basic_blocks([op], [x], 8))
     tu = timeit(lambda: e.conv(p2, e.conv(p1, x, relu=True), res=x, relu=True))
-    print('n=%3d  ring kernel %6.1f us (%4.0f TF/s)   two launches %6.1f us (%4.0f TF/s)' % (n, tr, fl / tr / 1e6, tu, fl / tu / 1e6), flush=True)
+    print('n=%3d  two launches %6.1f us (%4.0f TF/s)' % (n, tu, fl / tu / 1e6), flush=True)
     for t in tiles:
         try:
             tt = timeit(lambda: e.basic_block2(op, x, t))
