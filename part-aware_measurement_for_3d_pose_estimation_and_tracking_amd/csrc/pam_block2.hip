@@ -314,8 +314,7 @@ constexpr int B96_NS = 27;                 // k-steps per convolution
 constexpr int B96_KIMG = 96 * 64;          // one k-step's weight image
 // M tiles per wave (conv1, conv2) are template parameters: <5, 4> takes items of up to 12 x 36 positions, <3, 2> half-size items
 constexpr int B96_TST = B96_NW * 16 * 64;  // byte distance between a wave's consecutive M tiles inside a chunk image (tile = wave + 4 i)
-constexpr int B96_NPW = 10;                // X pieces (16 slots x 64 B) per chunk and loader wave (waves 4-7): XSP <= 640 slots
-constexpr int B96_XSP_MAX = 16 * 4 * B96_NPW;
+constexpr int B96_XSP_MAX = 640;           // X slots per chunk image at most: 10 DMA pieces (16 slots x 64 B) per chunk and loader wave (waves 4-7)
 
 struct BB96Args {
     const uint16_t* in; const char* wpack; uint16_t* out;
@@ -330,8 +329,10 @@ __device__ __attribute__((aligned(256))) const uint32_t g_bb96_zero[64] = {0};
 #define B96_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // KPB = k-steps per ring barrier (2 or 4); the ring has 3 * KPB slots: the group being read, the one that has landed, the one in flight
-template <int MT1, int MT2, int KPB>
+// NPW = X pieces per chunk and loader wave: the item's XSP <= 64 NPW slots (a wave short of a piece re-sends its last one)
+template <int MT1, int MT2, int KPB, int NPW>
 __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
+    constexpr int B96_NPW = NPW;
     constexpr int RING = 3 * KPB, NG = (2 * B96_NS + KPB - 1) / KPB;     // ring slots; groups of KPB k-steps in the 54-step weight stream
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
@@ -632,19 +633,19 @@ static int launch_bb96(void* stream, const void* in, const void* wpack, void* ou
     a.inv_pwx = 1.0f / (float)(a.TC + 4); a.inv_pwi = 1.0f / (float)(a.TC + 2);
     // junk M tiles of conv1 read up to 2 rows + 2 slots past the last real slot of a chunk image: keep that inside the allocation
     // half-size items with room for it: a 12-slot ring and one barrier per four k-steps
-    const int kpb = (inst == 0 && (size_t)3 * a.xsp * 64 + 1024 + (size_t)12 * B96_KIMG <= 160 * 1024) ? 4 : 2;
+    const int kpb = (inst == 0 && a.xsp <= 64 * 7) ? 4 : 2;          // 3 x 448 x 64 + 1 KB + 72 KB fits 160 KB
     size_t lds = (size_t)3 * a.xsp * 64 + 1024 + (size_t)3 * kpb * B96_KIMG;
     const size_t reach = (size_t)2 * a.xsp * 64 + (size_t)(16 * B96_NW * kB96Inst[inst][0] + 2 * (a.TC + 4) + 3) * 64;
     if (reach > lds) lds = reach;
     if (lds > 160 * 1024) return PAM_E_ARG;
-    if (!pam_max_dynamic_lds((const void*)k_bblock2_96<5, 4, 2>, 160 * 1024) || !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 2>, 160 * 1024) ||
-        !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 4>, 160 * 1024)) return PAM_E_HIP;
+    if (!pam_max_dynamic_lds((const void*)k_bblock2_96<5, 4, 2, 10>, 160 * 1024) || !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 2, 10>, 160 * 1024) ||
+        !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 4, 7>, 160 * 1024)) return PAM_E_HIP;
 #ifdef PAM_DIAG
     a.stamps = g_bb2_stamps;
 #endif
-    if (inst == 0 && kpb == 4) pam_launch(k_bblock2_96<3, 2, 4>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
-    else if (inst == 0) pam_launch(k_bblock2_96<3, 2, 2>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
-    else pam_launch(k_bblock2_96<5, 4, 2>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    if (inst == 0 && kpb == 4) pam_launch(k_bblock2_96<3, 2, 4, 7>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    else if (inst == 0) pam_launch(k_bblock2_96<3, 2, 2, 10>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    else pam_launch(k_bblock2_96<5, 4, 2, 10>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 

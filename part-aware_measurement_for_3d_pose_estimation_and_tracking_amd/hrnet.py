@@ -326,6 +326,7 @@ class HRNetPose(object):
         self.autotune = bool(autotune) and backend == 'hip' and use_graph
         self.tuned = {}                                   # crop count -> {'choice': configuration name} of every replay captured so far
         self._kp_pinned = {}         # crop count -> two pinned host buffers for predict()'s keypoints
+        self._meta_pinned = {}       # table size -> two pinned staging buffers for predict()'s per-call tables
         # activations of the captured forwards: one arena per replay slot, sized for max_crops crops per forward (a larger forward gets a
         # new, larger arena; the captures made before keep theirs) -- hrnet_hip.ActivationArena
         self.max_crops = int(max_crops)
@@ -539,7 +540,13 @@ class HRNetPose(object):
         meta[6 * n:6 * n + V] = cnt
         o_ptr = 6 * n + V + (V & 1)
         meta[o_ptr:].view(np.int64)[:] = [frames[v].data_ptr() if v in frames else 0 for v in range(V)]
-        m = torch.from_numpy(meta).to(self.device, non_blocking=True)
+        # staged through a pinned buffer of its own (two per size, alternating): the upload is asynchronous and the host goes on issuing
+        stage = self._meta_pinned.setdefault(meta.size, [])
+        if len(stage) < 2:
+            stage.append(torch.empty(meta.size, dtype=torch.int32).pin_memory())
+        stage.reverse()
+        stage[0].numpy()[:] = meta
+        m = stage[0].to(self.device, non_blocking=True)
         view_of, slot_of = m[:n], m[n:2 * n]
         bx = m[2 * n:6 * n].view(torch.float32).reshape(n, 4)
         n_det = m[6 * n:6 * n + V]

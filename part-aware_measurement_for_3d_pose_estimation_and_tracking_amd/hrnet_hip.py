@@ -640,6 +640,13 @@ class HipHRNet(ConvEngine):
             self.arena.epoch()
 
     def _features(self, x8):
+        x = self._head(x8)
+        if self.stop_after in ('stem', 'layer1'):
+            return x
+        return self._body(x)
+
+    def _head(self, x8):
+        """stem + layer1: one dependent chain on the caller's stream -> the (N, 256, H/4, W/4) tensor the branches start from"""
         self._epoch()
         x = self.conv(self.conv1, x8, relu=True)
         x = self.conv(self.conv2, x, relu=True)
@@ -660,8 +667,10 @@ class HipHRNet(ConvEngine):
                 y = self.conv(b['c1'], x, relu=True)
                 y = self.conv(b['c2'], y, relu=True)
                 x = self.conv(b['c3'], y, res=r, relu=True)
-        if self.stop_after == 'layer1':
-            return x
+        return x
+
+    def _body(self, x):
+        """stages 2-4 on the branch streams"""
         self._barrier()                                               # fork: branch streams must see layer1's output
         xs = [('lazy', self.t1[0], x), ('lazy', self.t1[1], x)]
         for m in self.stage2:

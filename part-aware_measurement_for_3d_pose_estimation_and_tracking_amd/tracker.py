@@ -77,6 +77,11 @@ class IterativeTracker(object):
         self.cam_num = n_views
         self._ndet = np.zeros((1, n_views), dtype=np.int32)
         self._det = np.zeros((1, n_views, self.max_dets, NUM_JOINTS, 3), dtype=np.float64)
+        # the record of the device-side step lands in PINNED host memory: a pageable destination makes the copy a staged, blocking one
+        import torch
+        L = self.handle.layout
+        self._rec_i = torch.zeros((1, L.int_words), dtype=torch.int32).pin_memory()
+        self._rec_d = torch.zeros((1, L.dbl_words), dtype=torch.float64).pin_memory()
 
     def set_cameras(self, cameras):
         if self.handle is None or self.cam_num != len(cameras):
@@ -122,9 +127,10 @@ class IterativeTracker(object):
             raise _lib.PamError('device detections %s do not match the tracker (%d views, max_dets=%d)' % (tuple(dev_det.shape), self.cam_num, self.max_dets))
         st = torch.cuda.current_stream(dev_det.device).cuda_stream
         self.handle.frame_dev(st, frame_id, dev_n_det.data_ptr(), dev_det.data_ptr())
-        self.handle.fetch(st)
+        oi, od = self._rec_i.numpy(), self._rec_d.numpy()
+        self.handle.fetch(st, oi, od)
         self.handle.sync(st)
-        self.last = self.handle.decode(0)
+        self.last = self.handle.decode(0, oi, od)
         if self.last['status'] != 0:
             raise _lib.PamError('tracker status 0x%x (capacity overflow / infeasible assignment) on frame %d' % (self.last['status'], frame_id))
         self.tracks = [TrackView(r, self.cameras, None) for r in self.last['tracks']]

@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes over ONE layer of every kernel family of the HRNet conv stack (20 crops), summarised to one JSON
 # (profiles/rNN_pmc_families.json).  Counters in their own runs (no tracing), several passes: SQ has 8 slots, TCC 4.
 # usage (GPU box, through gpurun): tools/pmc_families.sh <git commit> [round tag]
-COMMIT=${1:-unknown}; TAG=${2:-r03}
+COMMIT=${1:-unknown}; TAG=${2:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_fam; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"
@@ -11,11 +11,9 @@ P3="FETCH_SIZE"
 P4="WRITE_SIZE GRBM_GUI_ACTIVE"
 # name | bench_conv_one arguments
 FAMS=(
- "k_bblock_C48_96x72|--shape 96,72,48,48,3,1 --block 1"
- "k_bblock_C96_48x36|--shape 48,36,96,96,3,1 --block 1"
- "k_bblock_C192_24x18|--shape 24,18,192,192,3,1 --block 1"
- "k_conv3x3_C48_96x72|--shape 96,72,48,48,3,1"
- "k_conv3x3_C96_48x36|--shape 48,36,96,96,3,1"
+ "k_bblock2_48_96x72|--shape 96,72,48,48,3,1 --block 1"
+ "k_bblock2_96_48x36|--shape 48,36,96,96,3,1 --block 1"
+ "k_conv3x3s_C96_48x36|--shape 48,36,96,96,3,1"
  "k_conv3x3s_C192_24x18|--shape 24,18,192,192,3,1"
  "k_conv3x3s_C384_12x9|--shape 12,9,384,384,3,1"
  "k_conv_gs96_3x3s2_48to192_96x72|--shape 96,72,48,192,3,2 --res 0"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of one HRNet forward (20 crops) from rocprofv3 PMC counters: separate passes for FETCH_SIZE and WRITE_SIZE.
 # usage (on the GPU box, through gpurun): tools/pmc_hrnet.sh <git commit of the build> [round tag]
-COMMIT=${1:-unknown}; TAG=${2:-r03}; CONFIG=${3:-grouped}       # CONFIG: the executor configuration bench.py's autotuner chose for 20 crops
+COMMIT=${1:-unknown}; TAG=${2:-r04}; CONFIG=${3:-fused48_fused96}       # CONFIG: the executor configuration of the 20-crop replay (HRNetPose.config_for)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_hrnet; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 for P in FETCH_SIZE WRITE_SIZE; do

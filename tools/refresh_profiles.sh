@@ -2,14 +2,14 @@
 # Round-end artefacts (GPU box, through gpurun): bench line, the same command under rocprofv3 --kernel-trace --stats, PMC passes
 # (whole-forward HBM traffic, per-family counters), the N = 2 bench on one device.  usage: tools/refresh_profiles.sh <git commit> <tag> [light]
 # light: only the bench line, the same command under rocprofv3 and the N = 2 run (kernels unchanged since the last PMC passes)
-COMMIT=${1:-unknown}; TAG=${2:-r03}; MODE=${3:-full}
+COMMIT=${1:-unknown}; TAG=${2:-r04}; MODE=${3:-full}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/final; mkdir -p $OUT
 cd $R
 # the executor configuration the autotuner picks for 20 crops on THIS box (a short bench run), then the whole-forward HBM counters in it
 CONFIG=$(python3 bench.py --steps 10 --warmup 4 --no-cpu-baseline --no-families --no-surface --no-batched --no-drift --no-pair --no-h2d 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(j['config']['conv_executor']['20']['choice'])")
 echo "executor configuration for 20 crops: $CONFIG"
 if [ $MODE = full ]; then
-bash tools/pmc_hrnet.sh $COMMIT $TAG ${CONFIG:-grouped} > $OUT/pmc_hrnet.log 2>&1
+bash tools/pmc_hrnet.sh $COMMIT $TAG ${CONFIG:-fused48_fused96} > $OUT/pmc_hrnet.log 2>&1
 cp gpurun_out/pmc_hrnet/${TAG}_hrnet_hbm_traffic.json profiles/ 2>/dev/null
 fi       # bench.py stamps roofline.traffic from the newest one
 python3 bench.py > $OUT/${TAG}_bench_S2_n1.json 2> $OUT/bench.err
