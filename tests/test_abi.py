@@ -133,3 +133,17 @@ def test_bench_inputs_of_every_rank_for_the_shelf_frame_on_eight_ranks():
                 e = i['per_frame'][0]
                 assert i['frames'] == [] and int(i['ptrs'].numel()) == 1 and e['vl'].numel() == 0 and e['nd'].numel() == 0
                 assert tuple(e['bx'].shape) == (0, 4) and tuple(e['dd'].shape) == (1, max_dets, 17, 3)
+
+
+def test_algorithmic_work_is_executor_independent_and_launch_counts_follow_the_configuration():
+    """bench.py's roofline inputs (hrnet.algorithmic_work, a shape-only walk): the algorithmic bytes and FLOPs of a forward do not depend
+    on what the executor fuses -- un-fusing cannot raise a roofline fraction -- while launches and bytes-as-executed do; the
+    counts are the ones bench.py asserts against the recorded families."""
+    from pam import hrnet, hrnet_hip
+    w = {name: hrnet.algorithmic_work(20, config=name) for name in hrnet_hip.HipHRNet.CONFIGS}
+    a, b = w['fused48_fused96'], w['resident48_streamed96']
+    assert a['bytes'] == b['bytes'] and a['flops'] == b['flops']
+    assert abs(a['flops'] / (20 * hrnet.count_flops()) - 1) < 5e-3   # the stem's padded input channels (8 for 3) are the difference
+    assert a['launches'] == 227 and b['launches'] == 259 and a['bytes_as_executed'] < b['bytes_as_executed']
+    assert a['bytes'] < a['bytes_as_executed']                       # the deep branches' block interiors are traffic only as executed
+    assert hrnet.algorithmic_work(40)['bytes'] > 1.9 * a['bytes']    # activations scale with the crops, the weights do not

@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes over k_frame (the fused matching / triangulation / tracking kernel): S2 x 1 scene, S4 x 1 scene, S2 x 2048 scenes.
 # Counters in their own runs (no tracing), the program directly behind `--`.  -> gpurun_out/pmc_frame/<TAG>_pmc_k_frame.json
 # usage (GPU box, through gpurun): tools/pmc_frame.sh <git commit> [round tag]
-COMMIT=${1:-unknown}; TAG=${2:-r03}
+COMMIT=${1:-unknown}; TAG=${2:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_frame; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
