@@ -277,6 +277,17 @@ int pam_basic_block2_nhwc_bf16(void* stream, const void* in, const void* wpack, 
  *   piece p holds, with q = p ^ ((row >> 1) & 7), h = q >> 2, g = q & 3, the input channels 64 sl + 16 g + 8 h .. + 7.
  * tile_cfg: 16-pixel tiles per wave tile (1..3), <= 0 = automatic.  replaces: conv3 + bn3 + residual + relu and the next conv1 + bn1 +
  * relu of the official Bottleneck (the HRNet backend is absent from the reference: call sites /root/reference/src/ivclabpose.py:131-132,210). */
+/* Round 4: HRNet's stem and the first Bottleneck's conv1 as ONE launch (csrc/pam_stem.hip):
+ *   c1 = ReLU(conv3x3 s2 p1 (in; 8 -> 64) + bias1), x0 = ReLU(conv3x3 s2 p1 (c1; 64 -> 64) + bias2), y1 = ReLU(conv1x1 (x0; 64 -> 64) + biasp);
+ * c1 stays in LDS.  in (N, H, W, 8) bf16 NHWC, out_x0 / out_y1 (N, H2, W2, 64) with H1 = (H - 1) / 2 + 1, H2 = (H1 - 1) / 2 + 1 (W alike).
+ * w1frag: the 8 -> 64 layer's w_img of pam_conv2d_nhwc_bf16 (k_conv_stem's A fragments, [4][3][64 lanes][8]); wp_img / biasp:
+ * pam_pointwise64_relu_nhwc_bf16's; w2img [9 taps][64 rows][64 K] bf16: row 16 j + q of a tap = output channel
+ * 32 (j >> 1) + 8 (q >> 2) + 4 (j & 1) + (q & 3), the row's 16-byte piece at position p holds input channels 8 c .. 8 c + 7 with
+ * c = p ^ ((q >> 1) & 7).  Results are bit-identical to the three launches it replaces (pam_conv2d_nhwc_bf16 twice, then
+ * pam_pointwise64_relu_nhwc_bf16).  replaces: conv1/bn1/relu, conv2/bn2/relu and layer1[0].conv1/bn1/relu of the official pose_hrnet (the
+ * HRNet backend is absent from the reference: call sites /root/reference/src/ivclabpose.py:131-132,210). */
+int pam_stem_fused_nhwc_bf16(void* stream, const void* in, const void* w1frag, const float* bias1, const void* w2img, const float* bias2,
+                             const void* wp_img, const float* biasp, void* out_x0, void* out_y1, int N, int H, int W);
 /* y = ReLU(W . x + bias), 64 -> 64 channels, pointwise (the first Bottleneck's conv1 on the stem output): w_img [64 rows][64 K] bf16, row
  * 16 jt + qq = output channel 16 (qq >> 2) + 4 jt + (qq & 3), natural K order, the row's 16-byte piece at position p holds K values
  * 8 q .. 8 q + 7 with q = p ^ ((row >> 1) & 7). */

@@ -74,10 +74,10 @@ struct BB2Args {
 __device__ __attribute__((aligned(64))) const uint32_t g_bb2_zero[16] = {0};
 
 __device__ __forceinline__ int fdiv_small(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }   // exact for x < 2^16
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {     // one v_cvt_pk_bf16_f32 (RNE); the cast form compiles to two converts + a permute
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {     // one v_cvt_pk_bf16_f32 (RNE).  The element-wise cast form compiles to two
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;           // converts + a permute; an asm statement is one instruction too but the compiler
+    typedef __attribute__((ext_vector_type(2))) float f32x2;               // does not pad it against the MFMA that wrote lo / hi (csrc/pam_stem.hip met that)
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, bf16x2_t));
 }
 __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {           // bf16 is sign-magnitude: max(int16, 0) clears the negatives
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));

@@ -1,0 +1,296 @@
+// libpam_hip.so, stem part of a1 (round 4): HRNet's stem and the first pointwise convolution of layer1 as ONE kernel
+//     c1 = ReLU(conv3x3 s2 (x;  8 -> 64) + b1)          384 x 288 -> 192 x 144     (x = the cropped person, RGB + 5 zero channels)
+//     x0 = ReLU(conv3x3 s2 (c1; 64 -> 64) + b2)         192 x 144 ->  96 x 72
+//     y1 = ReLU(conv1x1    (x0; 64 -> 64) + bp)         the first Bottleneck's conv1
+// Call site this stands for: the absent HRNet backend inside HRNetPose.predict, /root/reference/src/ivclabpose.py:210 (SURVEY.md
+// section 8, row a1).  As three launches (k_conv_stem, k_conv_gs, k_pw1) the chain is 21 + 38 + 10 us of a 20-crop forward plus two
+// launch boundaries, all of it serial in front of every branch, and c1 (71 MB at 20 crops) is written once and gathered 2.25 times.
+// Here c1 never leaves the CU.
+//
+// Work item = a 16 x 8 tile of x0 (persistent workgroups, one per CU, 8 waves):
+//   1. conv1 on the 33 x 17 positions of c1 the tile's windows touch (561 positions = 36 wave tiles of 16; 10 % recomputed in the
+//      halo).  As in k_conv_stem one MFMA covers a tap row (3 taps x 8 channels = 24 <= 32), the B fragment is the lane's 16-byte input
+//      pixel straight from global memory -- requested a whole item ahead, under the previous item's second convolution -- and the 12 weight
+//      fragments stay in registers.  The result (zero outside c1: conv2's padding) goes to LDS, 128 B per position.
+//   2. conv2 from LDS: wave w owns x0 rows 2 w, 2 w + 1 of the tile (16 pixels), 4 N tiles, K = 9 taps x 64 channels = 18 k-steps.
+//      c1's columns are stored by parity (even columns, then odd ones, rows 20 slots apart) so that the 16 pixels of a stride-2
+//      window read 2 x 8 CONSECUTIVE slots: with the usual piece swizzle (piece ^ (slot >> 1)) every fragment read is
+//      conflict-free.  conv2's weights (72 KB, [tap][64 rows][128 B], pieces swizzled the same way) are resident in LDS.
+//   3. the accumulators (+ bias, ReLU, one bf16 rounding) are x0 -- stored -- AND the B fragments of the pointwise product: conv2's
+//      weight rows are permuted so that lane group g ends with channels 32 h + 8 g .. + 7 (h = 0, 1), which is the natural K order of
+//      k_pw1; its 8 weight fragments sit in registers.
+// Same operand order per output element as the three kernels it replaces: results are bit-identical to theirs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pam.h"
+#include "pam_launch.hpp"
+
+// Diagnostic build only (tools/stamp_stem.py compiles this file with -DPAM_DIAG): per-wave s_memtime stamps into a buffer of their own.
+#ifdef PAM_DIAG
+static unsigned long long* g_stem_stamps = nullptr;
+extern "C" int pam_stem_debug_stamps(void* dev_buf) { g_stem_stamps = (unsigned long long*)dev_buf; return PAM_OK; }
+#define STEM_STAMP(k) do { if (a.stamps && lane == 0 && it < 6) a.stamps[(((size_t)blockIdx.x * 8 + wave) * 6 + it) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STEM_STAMP(k) do { } while (0)
+#endif
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+#define OOB_OFFSET 0x80000000u
+
+constexpr int TR = 16, TC = 8;                         // x0 tile
+constexpr int RH = 2 * TR + 1, RW = 2 * TC + 1;        // c1 positions under it: 33 x 17
+constexpr int RP = 20, ODD = 10;                       // slots per c1 row; first slot of the odd columns
+constexpr int NPOS = RH * RW, NPT1 = (NPOS + 15) / 16; // 561 positions, 36 wave tiles
+constexpr int MAXT1 = (NPT1 + 7) / 8;                  // conv1 wave tiles per wave (waves 0-3: 5, waves 4-7: 4)
+constexpr int W2B = 9 * 64 * 128;                      // conv2 image
+constexpr int LDS_BYTES = W2B + RH * RP * 128;         // 73 728 + 84 480 (+ 768 B of biases behind it)
+
+struct StemFArgs {
+    const uint16_t* in; const uint16_t* w1frag; const float* b1; const char* w2img; const float* b2; const char* wp; const float* bp;
+    uint16_t* x0; uint16_t* y1;
+    int N, H, W, H1, W1, H2, W2, tiles_y, tiles_x, ntiles;
+#ifdef PAM_DIAG
+    unsigned long long* stamps;
+#endif
+};
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {      // one v_cvt_pk_bf16_f32 (RNE) the compiler can see: as an asm
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;            // statement it is not padded against the MFMA that wrote lo / hi
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, bf16x2_t));
+}
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+}
+
+__global__ __launch_bounds__(512, 1) void k_stem_fused(StemFArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const region = smem + W2B;
+    const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // conv2's weight image: 72 pieces of 1 KiB, nine per wave, already in LDS order
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int piece = wave + 8 * i;
+        __builtin_amdgcn_global_load_lds((glb_void*)(a.w2img + piece * 1024 + lane * 16), (lds_void*)(smem + piece * 1024), 16, 0, 0);
+    }
+    const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * 16), 0x00020000);
+    bf16x8 wf1[4][3];                                   // conv1: A fragments [N tile][tap row]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) wf1[j][ky] = *(const bf16x8*)(a.w1frag + ((size_t)(j * 3 + ky) * 64 + lane) * 8);
+    bf16x8 wfp[2][4];                                   // pointwise: A fragments [k-step][N tile] (k_pw1's image)
+    {
+        const unsigned s3 = (unsigned)p >> 1;
+        const unsigned fo0 = (unsigned)p * 128 + (((unsigned)g ^ (s3 & 3)) << 4) + ((s3 >> 2) << 6);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wfp[h][j] = *(const bf16x8*)(a.wp + j * 2048 + (h ? (fo0 ^ 64u) : fo0));
+    }
+    // the three bias vectors live in LDS (768 B behind the c1 tile): a global load inside the item loop would queue behind the next
+    // item's input prefetch and stall its consumer for the whole prefetch
+    float* const bias_s = (float*)(smem + LDS_BYTES);
+    if (tid < 192) bias_s[tid] = tid < 64 ? a.b1[tid] : (tid < 128 ? a.b2[tid - 64] : a.bp[tid - 128]);
+
+    const int per_img = a.tiles_y * a.tiles_x;
+    bf16x8 xin[MAXT1][3];
+    unsigned okmask = 0;                                // bit i: this lane's position of wave tile i lies inside c1
+    // conv1's input pixels of item T -> registers (in flight)
+    auto issue_loads = [&](int T) {
+        const int n = T / per_img, r = T - n * per_img, R0 = (r / a.tiles_x) * TR, C0 = (r % a.tiles_x) * TC;
+        okmask = 0;
+        // all offsets first, then the loads back to back (flags combined with &, offsets computed unconditionally: with short-circuit
+        // conditions, or with the address arithmetic between the loads, the compiler serialises them with a vmcnt(0) wait per load)
+        unsigned off[MAXT1][3];
+#pragma unroll
+        for (int i = 0; i < MAXT1; ++i) {
+            const int t = wave + 8 * i;
+            const int P = 16 * t + p, ry = (P * 241) >> 12, rx = P - 17 * ry;              // P / 17, exact below 4096
+            const int cy = 2 * R0 - 1 + ry, cx = 2 * C0 - 1 + rx;
+            const bool ok1 = (P < NPOS) & ((unsigned)cy < (unsigned)a.H1) & ((unsigned)cx < (unsigned)a.W1);
+            okmask |= ok1 ? 1u << i : 0u;
+            const int ix = 2 * cx + g - 1;
+            const bool okx = ok1 & (g < 3) & ((unsigned)ix < (unsigned)a.W);
+            const unsigned col = (unsigned)ix * 16u;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = 2 * cy + ky - 1;
+                const unsigned rowb = (unsigned)(n * a.H + iy) * (unsigned)a.W * 16u;
+                off[i][ky] = (okx & ((unsigned)iy < (unsigned)a.H)) ? rowb + col : OOB_OFFSET;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MAXT1; ++i)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                xin[i][ky] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off[i][ky], 0, 0));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // conv2 fragment addresses: pixel (2 wave + (p >> 3), p & 7) of the tile
+    unsigned boff[9];
+    {
+        const int base = (2 * (2 * wave + (p >> 3))) * RP + (p & 7);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int slot = base + ky * RP + (kx == 1 ? ODD : (kx == 2 ? 1 : 0));
+                boff[ky * 3 + kx] = (unsigned)(W2B + slot * 128 + ((g ^ ((slot >> 1) & 7)) << 4));
+            }
+    }
+    const unsigned aoff = (unsigned)(p * 128 + ((g ^ (p >> 1)) << 4));
+
+    int T = blockIdx.x;
+    if (T < a.ntiles) issue_loads(T);
+    __syncthreads();                                     // the biases are in LDS
+    for (int it = 0; T < a.ntiles; T += gridDim.x, ++it) {
+        STEM_STAMP(0);
+        const int n = T / per_img, r = T - n * per_img, R0 = (r / a.tiles_x) * TR, C0 = (r % a.tiles_x) * TC;
+        // ---- conv1 -> LDS -----------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < MAXT1; ++i) {
+            const int t = wave + 8 * i;
+            if (t < NPT1) {
+                f32x4 acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = *(const f32x4*)(bias_s + 16 * g + 4 * j);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf1[j][ky]), __builtin_bit_cast(bf16x8_t, xin[i][ky]), acc[j], 0, 0, 0);
+                const int P = 16 * t + p, ry = (P * 241) >> 12, rx = P - 17 * ry;
+                // ReLU on the packed pair (bf16 is sign-magnitude: the same bits as k_conv_stem's fmaxf-then-round for every finite value),
+                // positions outside c1 zeroed by a mask: no branches
+                const uint32_t m = 0u - ((okmask >> i) & 1u);
+                uint32_t d[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    d[2 * j] = relu_bf16x2(pack_bf16x2(acc[j][0], acc[j][1])) & m;
+                    d[2 * j + 1] = relu_bf16x2(pack_bf16x2(acc[j][2], acc[j][3])) & m;
+                }
+                if (P < NPOS) {
+                    const int slot = ry * RP + ((rx & 1) ? ODD + (rx >> 1) : (rx >> 1)), sw = (slot >> 1) & 7;
+                    char* dst = region + slot * 128;
+                    *(u32x4*)(dst + (((2 * g) ^ sw) << 4)) = (u32x4){d[0], d[1], d[2], d[3]};
+                    *(u32x4*)(dst + (((2 * g + 1) ^ sw) << 4)) = (u32x4){d[4], d[5], d[6], d[7]};
+                }
+            }
+        }
+        STEM_STAMP(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first item: conv2's weights have landed (later: nothing is in flight here)
+        __syncthreads();                                 // c1 tile complete
+        STEM_STAMP(2);
+        if (T + (int)gridDim.x < a.ntiles) issue_loads(T + (int)gridDim.x);
+        // ---- conv2 from LDS ---------------------------------------------------------------------------------------------------
+        f32x4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = *(const f32x4*)(bias_s + 64 + 8 * g + 32 * (j >> 1) + 4 * (j & 1));
+        bf16x8 af[2][4], bfr[2];
+        auto ld = [&](int s, bf16x8* a_, bf16x8& b_) {   // k-step s = (tap s >> 1, channels 32 (s & 1) ..)
+            const unsigned x = (s & 1) ? 64u : 0u;
+            b_ = *(const bf16x8*)(smem + (boff[s >> 1] ^ x));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a_[j] = *(const bf16x8*)(smem + (s >> 1) * 8192 + j * 2048 + (aoff ^ x));
+        };
+        ld(0, af[0], bfr[0]);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s + 1 < 18) ld(s + 1, af[nxt], bfr[nxt]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[cur][j]), __builtin_bit_cast(bf16x8_t, bfr[cur]), acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        STEM_STAMP(3);
+        // ---- x0 out, pointwise product from the accumulators, y1 out -----------------------------------------------------------
+        u32x4 xf[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            xf[h] = (u32x4){relu_bf16x2(pack_bf16x2(acc[2 * h][0], acc[2 * h][1])), relu_bf16x2(pack_bf16x2(acc[2 * h][2], acc[2 * h][3])),
+                            relu_bf16x2(pack_bf16x2(acc[2 * h + 1][0], acc[2 * h + 1][1])), relu_bf16x2(pack_bf16x2(acc[2 * h + 1][2], acc[2 * h + 1][3]))};
+        f32x4 accp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) accp[j] = *(const f32x4*)(bias_s + 128 + 16 * g + 4 * j);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                accp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfp[h][j]), __builtin_bit_cast(bf16x8_t, xf[h]), accp[j], 0, 0, 0);
+        const int oy = R0 + 2 * wave + (p >> 3), ox = C0 + (p & 7);
+        if (oy < a.H2 && ox < a.W2) {
+            const size_t pix = ((size_t)n * a.H2 + oy) * a.W2 + ox;
+            char* xo = (char*)a.x0 + pix * 128 + g * 16;
+            *(u32x4*)xo = xf[0];
+            *(u32x4*)(xo + 64) = xf[1];
+            uint32_t o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] = relu_bf16x2(pack_bf16x2(accp[j][0], accp[j][1]));
+                o[2 * j + 1] = relu_bf16x2(pack_bf16x2(accp[j][2], accp[j][3]));
+            }
+            char* yo = (char*)a.y1 + pix * 128 + g * 32;
+            *(u32x4*)yo = (u32x4){o[0], o[1], o[2], o[3]};
+            *(u32x4*)(yo + 16) = (u32x4){o[4], o[5], o[6], o[7]};
+        }
+        STEM_STAMP(4);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading the c1 tile
+        STEM_STAMP(5);
+    }
+}
+
+}  // namespace
+
+// Images the host packs (bf16; layouts also in include/pam.h):
+//   w1frag [4 N tiles][3 tap rows][64 lanes][8]   k_conv_stem's A fragments (pam_conv2d_nhwc_bf16's w_img of the 8 -> 64 stem layer)
+//   w2img  [9 taps][64 rows][64 K]                row 16 j + q of a tap holds output channel 32 (j >> 1) + 8 (q >> 2) + 4 (j & 1) + (q & 3);
+//                                                 the row's 16-byte piece at PHYSICAL position pp holds input channels 8 c .. 8 c + 7 with c = pp ^ ((q >> 1) & 7)
+//   wp     [64 rows][64 K]                        pam_pointwise64_relu_nhwc_bf16's w_img
+extern "C" int pam_stem_fused_nhwc_bf16(void* stream, const void* in, const void* w1frag, const float* bias1, const void* w2img,
+                                        const float* bias2, const void* wp_img, const float* biasp, void* out_x0, void* out_y1,
+                                        int N, int H, int W) {
+    if (!in || !w1frag || !bias1 || !w2img || !bias2 || !wp_img || !biasp || !out_x0 || !out_y1 || N <= 0 || H < 4 || W < 4) return PAM_E_ARG;
+    if ((size_t)N * H * W * 16 >= (1ull << 31)) return PAM_E_ARG;
+    StemFArgs a;
+    a.in = (const uint16_t*)in; a.w1frag = (const uint16_t*)w1frag; a.b1 = bias1; a.w2img = (const char*)w2img; a.b2 = bias2;
+    a.wp = (const char*)wp_img; a.bp = biasp; a.x0 = (uint16_t*)out_x0; a.y1 = (uint16_t*)out_y1;
+    a.N = N; a.H = H; a.W = W;
+    a.H1 = (H - 1) / 2 + 1; a.W1 = (W - 1) / 2 + 1; a.H2 = (a.H1 - 1) / 2 + 1; a.W2 = (a.W1 - 1) / 2 + 1;
+    a.tiles_y = (a.H2 + TR - 1) / TR; a.tiles_x = (a.W2 + TC - 1) / TC;
+    const long long nt = (long long)N * a.tiles_y * a.tiles_x;
+    if (nt >= (1ll << 30)) return PAM_E_ARG;
+    a.ntiles = (int)nt;
+#ifdef PAM_DIAG
+    a.stamps = g_stem_stamps;
+#endif
+    if (!pam_max_dynamic_lds((const void*)k_stem_fused, LDS_BYTES + 768)) return PAM_E_HIP;
+    int ncu = 256;
+    {
+        static thread_local int cached_dev = -1, cached_cu = 256;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            if (dev != cached_dev) {
+                hipDeviceProp_t pr;
+                if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) { cached_cu = pr.multiProcessorCount; cached_dev = dev; }
+            }
+            ncu = cached_cu;
+        }
+    }
+    const int grid = a.ntiles < ncu ? a.ntiles : ncu;
+    pam_launch(k_stem_fused, dim3(grid), dim3(512), LDS_BYTES + 768, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}

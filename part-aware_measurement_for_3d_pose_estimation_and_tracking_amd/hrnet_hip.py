@@ -204,6 +204,29 @@ class PackedPointwise64(object):
         self.b = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(64)).to(device).contiguous()
 
 
+class PackedStem(object):
+    """HRNet's stem (conv1 8 -> 64 s2, conv2 64 -> 64 s2) and layer1[0].conv1 (64 -> 64 1x1) packed for ``pam_stem_fused_nhwc_bf16``
+    (csrc/pam_stem.hip; layouts: include/pam.h): conv1 and the pointwise keep the images of their own kernels, conv2 gets the
+    [9 taps][64 rows][64 K] LDS image."""
+
+    def __init__(self, conv1_packed, conv2, pw_packed, device):
+        assert conv1_packed._stem is not None and conv1_packed.cout == 64 and conv1_packed.stride == 2
+        assert conv2.weight.shape == (64, 64, 3, 3) and conv2.stride[0] == 2 and conv2.padding[0] == 1
+        self.c1, self.pw = conv1_packed, pw_packed
+        R = torch.arange(64)
+        j, q = R // 16, R % 16
+        ch = 32 * (j >> 1) + 8 * (q >> 2) + 4 * (j & 1) + (q & 3)                                   # image row -> output channel
+        c = torch.arange(8)[None, :] ^ ((q >> 1) & 7)[:, None]                                      # [row][physical piece] -> logical piece
+        cin = (8 * c[:, :, None] + torch.arange(8)[None, None, :]).reshape(64, 64)                  # [row][physical K position] -> input channel
+        w = conv2.weight.detach().float()[ch]                                                       # [row][cin][ky][kx]
+        img = torch.zeros((9, 64, 64), dtype=torch.float32)
+        for ky in range(3):
+            for kx in range(3):
+                img[ky * 3 + kx] = torch.gather(w[:, :, ky, kx], 1, cin)
+        self.w2 = img.to(torch.bfloat16).to(device).contiguous()
+        self.b2 = (conv2.bias.detach().float() if conv2.bias is not None else torch.zeros(64)).to(device).contiguous()
+
+
 class ActivationArena(object):
     """Activations of the captured forwards of ONE replay slot: a bump allocator over one device buffer of two halves.  The executor
     calls ``epoch()`` at the start of the stem, of layer1's successor and of every HR module; an epoch allocates from the half the
@@ -359,6 +382,31 @@ class ConvEngine(object):
         self._prof_add(x, 'k_pw1 64->64 pointwise', (n, h, w), nbytes, flops, launch)
         return y
 
+    def stem_fused(self, op, x8):
+        """(x0, y1) = stem + the first Bottleneck's conv1 in one launch (k_stem_fused): bit-identical to conv(conv1), conv(conv2), pointwise64."""
+        n, c, h, w = x8.shape
+        assert c == 8
+        h2, w2 = ((h - 1) // 2 + 1 - 1) // 2 + 1, ((w - 1) // 2 + 1 - 1) // 2 + 1
+        x0 = self._new(n, 64, h2, w2, x8.device)
+        y1 = self._new(n, 64, h2, w2, x8.device)
+        h1, w1 = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        nbytes = 2 * (x8.numel() + x0.numel() + y1.numel() + 64 * 72 + 64 * 576 + 64 * 64) + 4 * 192
+        flops = 2 * n * (h1 * w1 * 64 * 72 + h2 * w2 * 64 * (576 + 64))
+        if self.count is not None:
+            self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
+        if x8.device.type == 'meta':
+            return x0, y1
+        assert x8.is_contiguous(memory_format=torch.channels_last)
+        launch = lambda: self.lib.pam_stem_fused_nhwc_bf16(
+            C.c_void_p(torch.cuda.current_stream(x8.device).cuda_stream), C.c_void_p(x8.data_ptr()), C.c_void_p(op.c1._stem.data_ptr()),
+            C.c_void_p(op.c1.bias.data_ptr()), C.c_void_p(op.w2.data_ptr()), C.c_void_p(op.b2.data_ptr()), C.c_void_p(op.pw.w.data_ptr()),
+            C.c_void_p(op.pw.b.data_ptr()), C.c_void_p(x0.data_ptr()), C.c_void_p(y1.data_ptr()), n, h, w)
+        rc = launch()
+        if rc != 0:
+            raise _lib.PamError('pam_stem_fused_nhwc_bf16 failed (%d) for %s' % (rc, tuple(x8.shape)))
+        self._prof_add(x8, 'k_stem_fused stem + conv1 of layer1', (n, h, w), nbytes, flops, launch)
+        return x0, y1
+
     def bottleneck_tail(self, op, y2, x0=None, res=None, tile_cfg=0):
         """X = ReLU(conv3(y2) [+ downsample(x0)] [+ res]); y1 = ReLU(conv1_next(X)) in one launch -> (X, y1 or None)."""
         n, c, h, w = y2.shape
@@ -454,6 +502,7 @@ class HipHRNet(ConvEngine):
         # the same blocks for the fused pointwise tail: tail b = conv3_b [+ downsample_0] + residual + ReLU, then conv1_{b+1} + ReLU
         l1 = list(m.layer1)
         self.pw0 = PackedPointwise64(l1[0].conv1, device)
+        self.stem = PackedStem(self.conv1, m.conv2, self.pw0, device)
         self.tails = [PackedTail(b.conv3, b.downsample[0] if b.downsample is not None else None,
                                  l1[i + 1].conv1 if i + 1 < len(l1) else None, device) for i, b in enumerate(l1)]
         self.t1 = [P(m.transition1[0][0]), P(m.transition1[1][0][0])]
@@ -626,6 +675,7 @@ class HipHRNet(ConvEngine):
 
     fuse_tail = True            # layer1: conv3 + residual + next conv1 of every Bottleneck in one launch (csrc/pam_pw.hip)
     tail_cfg = 0                # its wave-tile size (0 = automatic)
+    fuse_stem = True            # conv1 + conv2 + layer1[0].conv1 in one launch (csrc/pam_stem.hip; needs fuse_tail): -2.2 % at 20 crops, -1.5 % at 8, -2.5 % at 40
     stop_after = None           # diagnostics (tools/stage_times.py): 'stem' | 'layer1' | 'stage2' | 'stage3' -> the forward ends there
 
     def _end(self, xs):
@@ -648,20 +698,26 @@ class HipHRNet(ConvEngine):
     def _head(self, x8):
         """stem + layer1: one dependent chain on the caller's stream -> the (N, 256, H/4, W/4) tensor the branches start from"""
         self._epoch()
-        x = self.conv(self.conv1, x8, relu=True)
-        x = self.conv(self.conv2, x, relu=True)
-        if self.stop_after == 'stem':
-            return x
+        if self.fuse_stem and self.fuse_tail and self.stop_after != 'stem':
+            x0, y = self.stem_fused(self.stem, x8)
+        else:
+            x = self.conv(self.conv1, x8, relu=True)
+            x = self.conv(self.conv2, x, relu=True)
+            if self.stop_after == 'stem':
+                return x
+            x0, y = x, None
         if self.fuse_tail:
             # layer1 as 1 + 4 x 2 launches: conv1 of the first block, then per block the 3x3 and ONE pointwise-tail launch (conv3 + residual
             # / downsample + ReLU + the next block's conv1): the 256-channel tensor is written once and read once per block
-            x0, res = x, None
-            y = self.pointwise64(self.pw0, x0)
+            res = None
+            if y is None:
+                y = self.pointwise64(self.pw0, x0)
             for i, b in enumerate(self.layer1):
                 y2 = self.conv(b['c2'], y, relu=True)
                 x, y = self.bottleneck_tail(self.tails[i], y2, x0 if i == 0 else None, res, self.tail_cfg)
                 res = x
         else:
+            x = x0
             for b in self.layer1:
                 r = x if b['down'] is None else self.conv(b['down'], x)
                 y = self.conv(b['c1'], x, relu=True)
