@@ -204,6 +204,35 @@ class PackedPointwise64(object):
         self.b = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(64)).to(device).contiguous()
 
 
+def conv64_image(conv, device):
+    """[9 taps][64 rows][64 K] bf16 LDS image of a 64 -> 64 3x3 convolution for the fused stem / Bottleneck kernels (layout: include/pam.h):
+    row 16 j + q of a tap = output channel 32 (j >> 1) + 8 (q >> 2) + 4 (j & 1) + (q & 3) -- a lane then ends with channels 32 h + 8 g .. + 7,
+    the natural K order of the pointwise product that consumes its accumulators --, 16-byte pieces swizzled by (q >> 1) & 7."""
+    assert conv.weight.shape == (64, 64, 3, 3)
+    R = torch.arange(64)
+    j, q = R // 16, R % 16
+    ch = 32 * (j >> 1) + 8 * (q >> 2) + 4 * (j & 1) + (q & 3)                                   # image row -> output channel
+    c = torch.arange(8)[None, :] ^ ((q >> 1) & 7)[:, None]                                      # [row][physical piece] -> logical piece
+    cin = (8 * c[:, :, None] + torch.arange(8)[None, None, :]).reshape(64, 64)                  # [row][physical K position] -> input channel
+    w = conv.weight.detach().float()[ch]                                                        # [row][cin][ky][kx]
+    img = torch.zeros((9, 64, 64), dtype=torch.float32)
+    for ky in range(3):
+        for kx in range(3):
+            img[ky * 3 + kx] = torch.gather(w[:, :, ky, kx], 1, cin)
+    return img.to(torch.bfloat16).to(device).contiguous()
+
+
+class PackedBneck(object):
+    """A layer1 Bottleneck from its 3x3 convolution on, packed for ``pam_bottleneck_fused_nhwc_bf16`` (csrc/pam_bneck.hip): the 3x3's LDS
+    image + the pointwise tail's images (PackedTail with one K source)."""
+
+    def __init__(self, conv2, tail, device):
+        assert tail.S == 1 and conv2.stride[0] == 1 and conv2.padding[0] == 1
+        self.tail = tail
+        self.w2 = conv64_image(conv2, device)
+        self.b2 = (conv2.bias.detach().float() if conv2.bias is not None else torch.zeros(64)).to(device).contiguous()
+
+
 class PackedStem(object):
     """HRNet's stem (conv1 8 -> 64 s2, conv2 64 -> 64 s2) and layer1[0].conv1 (64 -> 64 1x1) packed for ``pam_stem_fused_nhwc_bf16``
     (csrc/pam_stem.hip; layouts: include/pam.h): conv1 and the pointwise keep the images of their own kernels, conv2 gets the
@@ -213,17 +242,7 @@ class PackedStem(object):
         assert conv1_packed._stem is not None and conv1_packed.cout == 64 and conv1_packed.stride == 2
         assert conv2.weight.shape == (64, 64, 3, 3) and conv2.stride[0] == 2 and conv2.padding[0] == 1
         self.c1, self.pw = conv1_packed, pw_packed
-        R = torch.arange(64)
-        j, q = R // 16, R % 16
-        ch = 32 * (j >> 1) + 8 * (q >> 2) + 4 * (j & 1) + (q & 3)                                   # image row -> output channel
-        c = torch.arange(8)[None, :] ^ ((q >> 1) & 7)[:, None]                                      # [row][physical piece] -> logical piece
-        cin = (8 * c[:, :, None] + torch.arange(8)[None, None, :]).reshape(64, 64)                  # [row][physical K position] -> input channel
-        w = conv2.weight.detach().float()[ch]                                                       # [row][cin][ky][kx]
-        img = torch.zeros((9, 64, 64), dtype=torch.float32)
-        for ky in range(3):
-            for kx in range(3):
-                img[ky * 3 + kx] = torch.gather(w[:, :, ky, kx], 1, cin)
-        self.w2 = img.to(torch.bfloat16).to(device).contiguous()
+        self.w2 = conv64_image(conv2, device)
         self.b2 = (conv2.bias.detach().float() if conv2.bias is not None else torch.zeros(64)).to(device).contiguous()
 
 
@@ -407,6 +426,34 @@ class ConvEngine(object):
         self._prof_add(x8, 'k_stem_fused stem + conv1 of layer1', (n, h, w), nbytes, flops, launch)
         return x0, y1
 
+    def bottleneck_fused(self, op, y1, res):
+        """(X, y1' or None) = conv3x3 + pointwise tail of a layer1 Bottleneck in one launch (k_bneck): bit-identical to conv(c2) + bottleneck_tail."""
+        n, c, h, w = y1.shape
+        t = op.tail
+        assert c == 64 and res is not None and tuple(res.shape) == (n, 256, h, w)
+        X = self._new(n, 256, h, w, y1.device)
+        Y = self._new(n, 64, h, w, y1.device) if t.w1 is not None else None
+        M = n * h * w
+        nbytes = 2 * (y1.numel() + res.numel() + X.numel() + (Y.numel() if Y is not None else 0) + 64 * 576 + 256 * 64 +
+                      (64 * 256 if t.w1 is not None else 0)) + 4 * (64 + 256 + (64 if t.w1 is not None else 0))
+        flops = 2 * M * (64 * 576 + 64 * 256 + (256 * 64 if t.w1 is not None else 0))
+        if self.count is not None:
+            self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
+        if y1.device.type == 'meta':
+            return X, Y
+        for q in (y1, res):
+            assert q.is_contiguous(memory_format=torch.channels_last)
+        launch = lambda: self.lib.pam_bottleneck_fused_nhwc_bf16(
+            C.c_void_p(torch.cuda.current_stream(y1.device).cuda_stream), C.c_void_p(y1.data_ptr()), C.c_void_p(res.data_ptr()),
+            C.c_void_p(op.w2.data_ptr()), C.c_void_p(op.b2.data_ptr()), C.c_void_p(t.w3.data_ptr()), C.c_void_p(t.b3.data_ptr()),
+            C.c_void_p(t.w1.data_ptr()) if t.w1 is not None else None, C.c_void_p(t.b1.data_ptr()) if t.w1 is not None else None,
+            C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()) if Y is not None else None, n, h, w)
+        rc = launch()
+        if rc != 0:
+            raise _lib.PamError('pam_bottleneck_fused_nhwc_bf16 failed (%d) for %s' % (rc, tuple(y1.shape)))
+        self._prof_add(y1, 'k_bneck 3x3 + bottleneck tail', (n, h, w, t.w1 is not None), nbytes, flops, launch)
+        return X, Y
+
     def bottleneck_tail(self, op, y2, x0=None, res=None, tile_cfg=0):
         """X = ReLU(conv3(y2) [+ downsample(x0)] [+ res]); y1 = ReLU(conv1_next(X)) in one launch -> (X, y1 or None)."""
         n, c, h, w = y2.shape
@@ -505,6 +552,7 @@ class HipHRNet(ConvEngine):
         self.stem = PackedStem(self.conv1, m.conv2, self.pw0, device)
         self.tails = [PackedTail(b.conv3, b.downsample[0] if b.downsample is not None else None,
                                  l1[i + 1].conv1 if i + 1 < len(l1) else None, device) for i, b in enumerate(l1)]
+        self.bnecks = [None] + [PackedBneck(b.conv2, self.tails[i], device) for i, b in enumerate(l1) if i > 0]
         self.t1 = [P(m.transition1[0][0]), P(m.transition1[1][0][0])]
         self.t2 = P(m.transition2[2][0][0])
         self.t3 = P(m.transition3[3][0][0])
@@ -675,6 +723,7 @@ class HipHRNet(ConvEngine):
 
     fuse_tail = True            # layer1: conv3 + residual + next conv1 of every Bottleneck in one launch (csrc/pam_pw.hip)
     tail_cfg = 0                # its wave-tile size (0 = automatic)
+    fuse_bneck = True           # blocks 1-3 of layer1: 3x3 + pointwise tail in one launch (csrc/pam_bneck.hip; needs fuse_tail): -3.0 % at 20 crops, -2.1 % at 8, -1.6 % at 40
     fuse_stem = True            # conv1 + conv2 + layer1[0].conv1 in one launch (csrc/pam_stem.hip; needs fuse_tail): -2.2 % at 20 crops, -1.5 % at 8, -2.5 % at 40
     stop_after = None           # diagnostics (tools/stage_times.py): 'stem' | 'layer1' | 'stage2' | 'stage3' -> the forward ends there
 
@@ -713,8 +762,11 @@ class HipHRNet(ConvEngine):
             if y is None:
                 y = self.pointwise64(self.pw0, x0)
             for i, b in enumerate(self.layer1):
-                y2 = self.conv(b['c2'], y, relu=True)
-                x, y = self.bottleneck_tail(self.tails[i], y2, x0 if i == 0 else None, res, self.tail_cfg)
+                if self.fuse_bneck and i > 0:
+                    x, y = self.bottleneck_fused(self.bnecks[i], y, res)
+                else:
+                    y2 = self.conv(b['c2'], y, relu=True)
+                    x, y = self.bottleneck_tail(self.tails[i], y2, x0 if i == 0 else None, res, self.tail_cfg)
                 res = x
         else:
             x = x0

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""us per call: the fused layer1 Bottleneck (k_bneck) against the two launches it replaces, captured 20x into one graph each (development tool)."""
+import os, sys, argparse
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+import pam
+from pam import _lib, hrnet_hip
+from test_gpu_bneck import make_convs
+
+ap = argparse.ArgumentParser(); ap.add_argument('--n', default='20'); ap.add_argument('--iters', type=int, default=20)
+args = ap.parse_args()
+dev = torch.device('cuda:0')
+e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); e.lib = _lib.load(); e.device = dev; e.tile_cfg = -1; e.c96_slab = 48
+c2, c3, c1n = make_convs(1)
+P2 = hrnet_hip.PackedConv(c2, dev)
+
+
+def timeit(fn, iters):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side): fn()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    g = torch.cuda.CUDAGraph(); keep = []
+    with torch.cuda.graph(g):
+        for _ in range(iters): keep.append(fn())
+    g.replay(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        a, b = torch.cuda.Event(True), torch.cuda.Event(True)
+        a.record(); g.replay(); b.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) / iters * 1e3)
+    return best
+
+
+for has2 in (True, False):
+    tail = hrnet_hip.PackedTail(c3, None, c1n if has2 else None, dev)
+    op = hrnet_hip.PackedBneck(c2, tail, dev)
+    for n in [int(v) for v in args.n.split(',')]:
+        cl = lambda t: t.to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
+        y1, res = cl(torch.relu(torch.randn((n, 64, 96, 72)))), cl(torch.relu(torch.randn((n, 256, 96, 72))))
+        two = lambda: e.bottleneck_tail(tail, e.conv(P2, y1, relu=True), None, res, 0)
+        t3 = timeit(lambda: e.conv(P2, y1, relu=True), args.iters)
+        print('n=%3d next-conv1=%d  3x3 alone %6.1f us, two launches %7.1f us   fused %7.1f us' % (n, has2, t3, timeit(two, args.iters), timeit(lambda: e.bottleneck_fused(op, y1, res), args.iters)), flush=True)
