@@ -291,13 +291,15 @@ int pam_stem_fused_nhwc_bf16(void* stream, const void* in, const void* w1frag, c
 /* Round 4: the 3x3 convolution of a layer1 Bottleneck and its pointwise tail as ONE launch (csrc/pam_bneck.hip):
  *   y2 = ReLU(conv3x3 s1 p1 (y1; 64 -> 64) + bias2), then pam_bottleneck_tail_nhwc_bf16's X = ReLU(W3 . y2 + bias3 + residual) and
  *   y1' = ReLU(W1 . X + bias1) (w1_img / bias1 / out_y1 all NULL: no second product); y2 never leaves the registers.
- * y1 (N, H, W, 64), residual / out_x (N, H, W, 256), out_y1 (N, H, W, 64), bf16 NHWC.  w2img: the [9 taps][64 rows][64 K] image of
- * pam_stem_fused_nhwc_bf16; w3_img (one K source) / w1_img: pam_bottleneck_tail_nhwc_bf16's.  Results are bit-identical to
+ * y1 (N, H, W, 64), residual / out_x (N, H, W, 256), out_y1 (N, H, W, 64), bf16 NHWC.  Exactly one of residual and x0 (N, H, W, 64: the
+ * FIRST block's input, whose 1x1 downsample convolution is the second K source of w3_img, as in pam_bottleneck_tail_nhwc_bf16) is given.
+ * w2img: the [9 taps][64 rows][64 K] image of pam_stem_fused_nhwc_bf16; w3_img (one K source, two with x0) / w1_img:
+ * pam_bottleneck_tail_nhwc_bf16's.  Results are bit-identical to
  * pam_conv2d_nhwc_bf16 (streamed 3x3 kernel) followed by pam_bottleneck_tail_nhwc_bf16.  replaces: conv2/bn2/relu, conv3/bn3 + residual +
  * relu and the next conv1/bn1/relu of the official Bottleneck (call sites /root/reference/src/ivclabpose.py:131-132,210). */
-int pam_bottleneck_fused_nhwc_bf16(void* stream, const void* y1, const void* residual, const void* w2img, const float* bias2,
-                                   const void* w3_img, const float* bias3, const void* w1_img, const float* bias1, void* out_x, void* out_y1,
-                                   int N, int H, int W);
+int pam_bottleneck_fused_nhwc_bf16(void* stream, const void* y1, const void* x0, const void* residual, const void* w2img,
+                                   const float* bias2, const void* w3_img, const float* bias3, const void* w1_img, const float* bias1,
+                                   void* out_x, void* out_y1, int N, int H, int W);
 /* y = ReLU(W . x + bias), 64 -> 64 channels, pointwise (the first Bottleneck's conv1 on the stem output): w_img [64 rows][64 K] bf16, row
  * 16 jt + qq = output channel 16 (qq >> 2) + 4 jt + (qq & 3), natural K order, the row's 16-byte piece at position p holds K values
  * 8 q .. 8 q + 7 with q = p ^ ((row >> 1) & 7). */

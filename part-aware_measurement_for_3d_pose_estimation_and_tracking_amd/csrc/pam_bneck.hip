@@ -42,7 +42,7 @@ static_assert(LDS_BYTES == 160 * 1024, "LDS map");
 constexpr int NLOAD = NPOS * 8;                        // 16-byte pieces of a y1 tile: 1440 = 2 x 512 + 416
 
 struct BnArgs {
-    const uint16_t* y1; const uint16_t* res; const char* w2img; const float* b2; const char* w3img; const float* b3;
+    const uint16_t* y1; const uint16_t* res; const uint16_t* x0; const char* w2img; const float* b2; const char* w3img; const float* b3;
     const char* w1img; const float* b1; uint16_t* outx; uint16_t* outy;
     int N, H, W, tiles_y, tiles_x, ntiles;
 };
@@ -58,7 +58,10 @@ __device__ __forceinline__ uint32_t relu_bf16x2(uint32_t v) {
 __device__ __forceinline__ float lo_f(uint32_t d) { return __builtin_bit_cast(float, d << 16); }
 __device__ __forceinline__ float hi_f(uint32_t d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
 
-template <bool HAS2>
+// HAS2: the next block's conv1 is computed; DOWN: the FIRST block -- no residual, instead the 1x1 downsample convolution over the block input x0 as a
+// second K range of the first product (w3img's second chunk; its 32 fragments live in registers: 32 KB
+// more do not fit LDS)
+template <bool HAS2, bool DOWN>
 __global__ __launch_bounds__(512, 1) void k_bneck(BnArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void k_bneck(BnArgs a) {
 
     const size_t npix = (size_t)a.N * a.H * a.W;
     const auto rs_y1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.y1, 0, (int)(npix * 128), 0x00020000);
-    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (int)(npix * 512), 0x00020000);
+    const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)(DOWN ? (const void*)a.x0 : (const void*)a.res), 0, (int)(npix * (DOWN ? 128 : 512)), 0x00020000);
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.outx, 0, (int)(npix * 512), 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS2 ? a.outy : a.outx), 0, (int)(npix * (HAS2 ? 128 : 512)), 0x00020000);
     const int per_img = a.tiles_y * a.tiles_x;
@@ -123,6 +126,18 @@ __global__ __launch_bounds__(512, 1) void k_bneck(BnArgs a) {
         }
     const unsigned aoff = (unsigned)(p * 128 + ((g ^ (p >> 1)) << 4));     // row p of a 16-row window, logical piece g (k-step 1: ^ 64)
 
+    // DOWN: the 32 downsample fragments (second chunk of w3img) stay in registers for the whole launch: 128 VGPRs that the kernel has to spare
+    bf16x8 wd[DOWN ? 32 : 1];
+    if constexpr (DOWN) {
+        const char* wdp = a.w3img + W3B;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wd[sl * 8 + h * 4 + j] = *(const bf16x8*)(wdp + (sl * 4 + j) * 2048 + (h ? (aoff ^ 64u) : aoff));
+    }
+
     int T = blockIdx.x;
     if (T < a.ntiles) region_issue(T);
     asm volatile("s_waitcnt vmcnt(3)" ::: "memory");     // the weight DMAs (older than the three tile loads) have landed
@@ -138,9 +153,15 @@ __global__ __launch_bounds__(512, 1) void k_bneck(BnArgs a) {
         const unsigned o512 = valid ? m * 512u + (unsigned)g * 32u : OOB_OFFSET, o128 = valid ? m * 128u + (unsigned)g * 32u : OOB_OFFSET;
         const bool has_next = T + (int)gridDim.x < a.ntiles;
         if (has_next) region_issue(T + (int)gridDim.x);
-        u32x4 rc[2], rn[2];
-        rc[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o512, 0, 0);
-        rc[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o512, 16, 0);
+        u32x4 rc[2], rn[2];                               // residual of the slab being computed / the next one (DOWN: x0's two B fragments in rc)
+        if constexpr (DOWN) {
+            const unsigned ox0 = valid ? m * 128u + (unsigned)g * 16u : OOB_OFFSET;
+            rc[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ox0, 0, 0);
+            rc[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, ox0, 64, 0);
+        } else {
+            rc[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o512, 0, 0);
+            rc[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o512, 16, 0);
+        }
         // ---- 3x3 convolution from LDS ------------------------------------------------------------------------------------------
         f32x4 acc[4];
 #pragma unroll
@@ -179,7 +200,8 @@ __global__ __launch_bounds__(512, 1) void k_bneck(BnArgs a) {
         }
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
-            if (sl < 3) {
+            if constexpr (DOWN) {
+            } else if (sl < 3) {
                 rn[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o512, (sl + 1) * 128, 0);
                 rn[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_res, o512, (sl + 1) * 128 + 16, 0);
             }
@@ -193,12 +215,24 @@ __global__ __launch_bounds__(512, 1) void k_bneck(BnArgs a) {
                     const bf16x8 wf = *(const bf16x8*)(smem + W3_OFF + (sl * 4 + j) * 2048 + (h ? (aoff ^ 64u) : aoff));
                     acc3[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, yb[h]), acc3[j], 0, 0, 0);
                 }
+            if constexpr (DOWN) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc3[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wd[sl * 8 + h * 4 + j]), __builtin_bit_cast(bf16x8_t, rc[h]), acc3[j], 0, 0, 0);
+            }
             uint32_t o[8];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t d0 = rc[j >> 1][(2 * j) & 3], d1 = rc[j >> 1][(2 * j + 1) & 3];
-                o[2 * j] = relu_bf16x2(pack_bf16x2(acc3[j][0] + lo_f(d0), acc3[j][1] + hi_f(d0)));
-                o[2 * j + 1] = relu_bf16x2(pack_bf16x2(acc3[j][2] + lo_f(d1), acc3[j][3] + hi_f(d1)));
+                if constexpr (DOWN) {
+                    o[2 * j] = relu_bf16x2(pack_bf16x2(acc3[j][0], acc3[j][1]));
+                    o[2 * j + 1] = relu_bf16x2(pack_bf16x2(acc3[j][2], acc3[j][3]));
+                } else {
+                    const uint32_t d0 = rc[j >> 1][(2 * j) & 3], d1 = rc[j >> 1][(2 * j + 1) & 3];
+                    o[2 * j] = relu_bf16x2(pack_bf16x2(acc3[j][0] + lo_f(d0), acc3[j][1] + hi_f(d0)));
+                    o[2 * j + 1] = relu_bf16x2(pack_bf16x2(acc3[j][2] + lo_f(d1), acc3[j][3] + hi_f(d1)));
+                }
             }
             const u32x4 xf[2] = {(u32x4){o[0], o[1], o[2], o[3]}, (u32x4){o[4], o[5], o[6], o[7]}};
             __builtin_amdgcn_raw_buffer_store_b128(xf[0], rs_x, o512, sl * 128, 0);
@@ -212,7 +246,7 @@ __global__ __launch_bounds__(512, 1) void k_bneck(BnArgs a) {
                         acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf), __builtin_bit_cast(bf16x8_t, xf[h]), acc1[j], 0, 0, 0);
                     }
             }
-            rc[0] = rn[0]; rc[1] = rn[1];
+            if constexpr (!DOWN) { rc[0] = rn[0]; rc[1] = rn[1]; }
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (HAS2) {
@@ -228,9 +262,9 @@ __global__ __launch_bounds__(512, 1) void k_bneck(BnArgs a) {
     }
 }
 
-template <bool HAS2>
+template <bool HAS2, bool DOWN>
 int launch_bneck(hipStream_t s, const BnArgs& a) {
-    if (!pam_max_dynamic_lds((const void*)k_bneck<HAS2>, LDS_BYTES)) return PAM_E_HIP;
+    if (!pam_max_dynamic_lds((const void*)k_bneck<HAS2, DOWN>, LDS_BYTES)) return PAM_E_HIP;
     int ncu = 256;
     {
         static thread_local int cached_dev = -1, cached_cu = 256;
@@ -244,25 +278,27 @@ int launch_bneck(hipStream_t s, const BnArgs& a) {
         }
     }
     const int grid = a.ntiles < ncu ? a.ntiles : ncu;
-    pam_launch(k_bneck<HAS2>, dim3(grid), dim3(512), LDS_BYTES, s, a);
+    pam_launch(k_bneck<HAS2, DOWN>, dim3(grid), dim3(512), LDS_BYTES, s, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
 }  // namespace
 
-// Images the host packs (bf16; layouts also in include/pam.h): w2img [9 taps][64 rows][64 K] as pam_stem_fused_nhwc_bf16's; w3_img (one
-// K source) / w1_img as pam_bottleneck_tail_nhwc_bf16's.
-extern "C" int pam_bottleneck_fused_nhwc_bf16(void* stream, const void* y1, const void* residual, const void* w2img, const float* bias2,
-                                              const void* w3_img, const float* bias3, const void* w1_img, const float* bias1,
-                                              void* out_x, void* out_y1, int N, int H, int W) {
-    if (!y1 || !residual || !w2img || !bias2 || !w3_img || !bias3 || !out_x || N <= 0 || H <= 0 || W <= 0) return PAM_E_ARG;
+// Images the host packs (bf16; layouts also in include/pam.h): w2img [9 taps][64 rows][64 K] as pam_stem_fused_nhwc_bf16's; w3_img (one K
+// source with a residual, two with x0) / w1_img as pam_bottleneck_tail_nhwc_bf16's.
+extern "C" int pam_bottleneck_fused_nhwc_bf16(void* stream, const void* y1, const void* x0, const void* residual, const void* w2img,
+                                              const float* bias2, const void* w3_img, const float* bias3, const void* w1_img,
+                                              const float* bias1, void* out_x, void* out_y1, int N, int H, int W) {
+    if (!y1 || (residual == nullptr) == (x0 == nullptr) || !w2img || !bias2 || !w3_img || !bias3 || !out_x || N <= 0 || H <= 0 || W <= 0) return PAM_E_ARG;
     if ((w1_img != nullptr) != (out_y1 != nullptr) || (w1_img && !bias1)) return PAM_E_ARG;
     if ((size_t)N * H * W * 512 >= (1ull << 31)) return PAM_E_ARG;
     BnArgs a;
-    a.y1 = (const uint16_t*)y1; a.res = (const uint16_t*)residual; a.w2img = (const char*)w2img; a.b2 = bias2; a.w3img = (const char*)w3_img;
-    a.b3 = bias3; a.w1img = (const char*)w1_img; a.b1 = bias1; a.outx = (uint16_t*)out_x; a.outy = (uint16_t*)out_y1;
+    a.y1 = (const uint16_t*)y1; a.res = (const uint16_t*)residual; a.x0 = (const uint16_t*)x0; a.w2img = (const char*)w2img; a.b2 = bias2;
+    a.w3img = (const char*)w3_img; a.b3 = bias3; a.w1img = (const char*)w1_img; a.b1 = bias1; a.outx = (uint16_t*)out_x; a.outy = (uint16_t*)out_y1;
     a.N = N; a.H = H; a.W = W;
     a.tiles_y = (H + TR - 1) / TR; a.tiles_x = (W + TC - 1) / TC;
     a.ntiles = N * a.tiles_y * a.tiles_x;
-    return w1_img ? launch_bneck<true>((hipStream_t)stream, a) : launch_bneck<false>((hipStream_t)stream, a);
+    hipStream_t s = (hipStream_t)stream;
+    if (x0) return w1_img ? launch_bneck<true, true>(s, a) : launch_bneck<false, true>(s, a);
+    return w1_img ? launch_bneck<true, false>(s, a) : launch_bneck<false, false>(s, a);
 }

@@ -227,7 +227,7 @@ class PackedBneck(object):
     image + the pointwise tail's images (PackedTail with one K source)."""
 
     def __init__(self, conv2, tail, device):
-        assert tail.S == 1 and conv2.stride[0] == 1 and conv2.padding[0] == 1
+        assert conv2.stride[0] == 1 and conv2.padding[0] == 1
         self.tail = tail
         self.w2 = conv64_image(conv2, device)
         self.b2 = (conv2.bias.detach().float() if conv2.bias is not None else torch.zeros(64)).to(device).contiguous()
@@ -426,32 +426,36 @@ class ConvEngine(object):
         self._prof_add(x8, 'k_stem_fused stem + conv1 of layer1', (n, h, w), nbytes, flops, launch)
         return x0, y1
 
-    def bottleneck_fused(self, op, y1, res):
-        """(X, y1' or None) = conv3x3 + pointwise tail of a layer1 Bottleneck in one launch (k_bneck): bit-identical to conv(c2) + bottleneck_tail."""
+    def bottleneck_fused(self, op, y1, res=None, x0=None):
+        """(X, y1' or None) = conv3x3 + pointwise tail of a layer1 Bottleneck in one launch (k_bneck): bit-identical to conv(c2) + bottleneck_tail.
+        res: the block input (blocks 1-3); x0: the first block's 64-channel input (its downsample convolution is part of the tail)."""
         n, c, h, w = y1.shape
         t = op.tail
-        assert c == 64 and res is not None and tuple(res.shape) == (n, 256, h, w)
+        assert c == 64 and (res is None) != (x0 is None) and (x0 is None) == (t.S == 1)
+        assert res is None or tuple(res.shape) == (n, 256, h, w)
         X = self._new(n, 256, h, w, y1.device)
         Y = self._new(n, 64, h, w, y1.device) if t.w1 is not None else None
         M = n * h * w
-        nbytes = 2 * (y1.numel() + res.numel() + X.numel() + (Y.numel() if Y is not None else 0) + 64 * 576 + 256 * 64 +
+        side = res if res is not None else x0
+        nbytes = 2 * (y1.numel() + side.numel() + X.numel() + (Y.numel() if Y is not None else 0) + 64 * 576 + t.S * 256 * 64 +
                       (64 * 256 if t.w1 is not None else 0)) + 4 * (64 + 256 + (64 if t.w1 is not None else 0))
-        flops = 2 * M * (64 * 576 + 64 * 256 + (256 * 64 if t.w1 is not None else 0))
+        flops = 2 * M * (64 * 576 + t.S * 64 * 256 + (256 * 64 if t.w1 is not None else 0))
         if self.count is not None:
             self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
         if y1.device.type == 'meta':
             return X, Y
-        for q in (y1, res):
+        for q in (y1, side):
             assert q.is_contiguous(memory_format=torch.channels_last)
         launch = lambda: self.lib.pam_bottleneck_fused_nhwc_bf16(
-            C.c_void_p(torch.cuda.current_stream(y1.device).cuda_stream), C.c_void_p(y1.data_ptr()), C.c_void_p(res.data_ptr()),
+            C.c_void_p(torch.cuda.current_stream(y1.device).cuda_stream), C.c_void_p(y1.data_ptr()),
+            C.c_void_p(x0.data_ptr()) if x0 is not None else None, C.c_void_p(res.data_ptr()) if res is not None else None,
             C.c_void_p(op.w2.data_ptr()), C.c_void_p(op.b2.data_ptr()), C.c_void_p(t.w3.data_ptr()), C.c_void_p(t.b3.data_ptr()),
             C.c_void_p(t.w1.data_ptr()) if t.w1 is not None else None, C.c_void_p(t.b1.data_ptr()) if t.w1 is not None else None,
             C.c_void_p(X.data_ptr()), C.c_void_p(Y.data_ptr()) if Y is not None else None, n, h, w)
         rc = launch()
         if rc != 0:
             raise _lib.PamError('pam_bottleneck_fused_nhwc_bf16 failed (%d) for %s' % (rc, tuple(y1.shape)))
-        self._prof_add(y1, 'k_bneck 3x3 + bottleneck tail', (n, h, w, t.w1 is not None), nbytes, flops, launch)
+        self._prof_add(y1, 'k_bneck 3x3 + bottleneck tail', (n, h, w, t.S, t.w1 is not None), nbytes, flops, launch)
         return X, Y
 
     def bottleneck_tail(self, op, y2, x0=None, res=None, tile_cfg=0):
@@ -552,7 +556,7 @@ class HipHRNet(ConvEngine):
         self.stem = PackedStem(self.conv1, m.conv2, self.pw0, device)
         self.tails = [PackedTail(b.conv3, b.downsample[0] if b.downsample is not None else None,
                                  l1[i + 1].conv1 if i + 1 < len(l1) else None, device) for i, b in enumerate(l1)]
-        self.bnecks = [None] + [PackedBneck(b.conv2, self.tails[i], device) for i, b in enumerate(l1) if i > 0]
+        self.bnecks = [PackedBneck(b.conv2, self.tails[i], device) for i, b in enumerate(l1)]
         self.t1 = [P(m.transition1[0][0]), P(m.transition1[1][0][0])]
         self.t2 = P(m.transition2[2][0][0])
         self.t3 = P(m.transition3[3][0][0])
@@ -723,6 +727,7 @@ class HipHRNet(ConvEngine):
 
     fuse_tail = True            # layer1: conv3 + residual + next conv1 of every Bottleneck in one launch (csrc/pam_pw.hip)
     tail_cfg = 0                # its wave-tile size (0 = automatic)
+    fuse_bneck0 = True          # the first block too (its downsample fragments live in registers: they do not fit LDS beside the rest): -0.7 % at 20 crops, -1.2 % at 8
     fuse_bneck = True           # blocks 1-3 of layer1: 3x3 + pointwise tail in one launch (csrc/pam_bneck.hip; needs fuse_tail): -3.0 % at 20 crops, -2.1 % at 8, -1.6 % at 40
     fuse_stem = True            # conv1 + conv2 + layer1[0].conv1 in one launch (csrc/pam_stem.hip; needs fuse_tail): -2.2 % at 20 crops, -1.5 % at 8, -2.5 % at 40
     stop_after = None           # diagnostics (tools/stage_times.py): 'stem' | 'layer1' | 'stage2' | 'stage3' -> the forward ends there
@@ -762,8 +767,8 @@ class HipHRNet(ConvEngine):
             if y is None:
                 y = self.pointwise64(self.pw0, x0)
             for i, b in enumerate(self.layer1):
-                if self.fuse_bneck and i > 0:
-                    x, y = self.bottleneck_fused(self.bnecks[i], y, res)
+                if self.fuse_bneck and (i > 0 or self.fuse_bneck0):
+                    x, y = self.bottleneck_fused(self.bnecks[i], y, res, x0 if i == 0 else None)
                 else:
                     y2 = self.conv(b['c2'], y, relu=True)
                     x, y = self.bottleneck_tail(self.tails[i], y2, x0 if i == 0 else None, res, self.tail_cfg)

@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser(); ap.add_argument('--n', default='20'); ap.add_arg
 args = ap.parse_args()
 dev = torch.device('cuda:0')
 e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); e.lib = _lib.load(); e.device = dev; e.tile_cfg = -1; e.c96_slab = 48
-c2, c3, c1n = make_convs(1)
+c2, c3, c1n, down = make_convs(1)
 P2 = hrnet_hip.PackedConv(c2, dev)
 
 
@@ -34,12 +34,14 @@ def timeit(fn, iters):
     return best
 
 
-for has2 in (True, False):
-    tail = hrnet_hip.PackedTail(c3, None, c1n if has2 else None, dev)
+for has2, first in ((True, False), (False, False), (True, True)):
+    tail = hrnet_hip.PackedTail(c3, down if first else None, c1n if has2 else None, dev)
     op = hrnet_hip.PackedBneck(c2, tail, dev)
     for n in [int(v) for v in args.n.split(',')]:
         cl = lambda t: t.to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last)
-        y1, res = cl(torch.relu(torch.randn((n, 64, 96, 72)))), cl(torch.relu(torch.randn((n, 256, 96, 72))))
-        two = lambda: e.bottleneck_tail(tail, e.conv(P2, y1, relu=True), None, res, 0)
+        y1 = cl(torch.relu(torch.randn((n, 64, 96, 72))))
+        res = cl(torch.relu(torch.randn((n, 256, 96, 72)))) if not first else None
+        x0 = cl(torch.relu(torch.randn((n, 64, 96, 72)))) if first else None
+        two = lambda: e.bottleneck_tail(tail, e.conv(P2, y1, relu=True), x0, res, 0)
         t3 = timeit(lambda: e.conv(P2, y1, relu=True), args.iters)
-        print('n=%3d next-conv1=%d  3x3 alone %6.1f us, two launches %7.1f us   fused %7.1f us' % (n, has2, t3, timeit(two, args.iters), timeit(lambda: e.bottleneck_fused(op, y1, res), args.iters)), flush=True)
+        print('n=%3d next-conv1=%d first=%d  3x3 alone %6.1f us, two launches %7.1f us   fused %7.1f us' % (n, has2, first, t3, timeit(two, args.iters), timeit(lambda: e.bottleneck_fused(op, y1, res, x0), args.iters)), flush=True)
