@@ -364,6 +364,8 @@ class ConvEngine(object):
         assert x.is_contiguous(memory_format=torch.channels_last)
         if tile is None and c == 96 and self.b96_tile:
             tile = tuple(self.b96_tile)
+        if tile is None and c == 48 and self.b48_tile:
+            tile = tuple(self.b48_tile)
         if tile is None:
             tile = self._bb2_tiles.get((c, n, h, w))
             if tile is None:
@@ -380,6 +382,7 @@ class ConvEngine(object):
         return y
 
     _bb2_tiles = {}             # (C, N, H, W) -> the library's tile choice (pam_basic_block2_tile searches ~H x W candidates)
+    b48_tile = None             # the same for the 48-channel block
     b96_tile = None             # (rows, cols) of the 96-channel fused block's items instead of the library's choice (tuning)
 
     def pointwise64(self, op, x):

@@ -19,8 +19,8 @@ for v in args.variants:
     hip = net.hip
     for kv in [q for q in spec.split(',') if q]:
         k, _, val = kv.partition('=')
-        if k == 'b96_tile':                            # e.g. b96_tile=12x36
-            hip.b96_tile = tuple(int(q) for q in val.split('x'))
+        if k in ('b96_tile', 'b48_tile'):                            # e.g. b96_tile=12x36
+            setattr(hip, k, tuple(int(q) for q in val.split('x')))
         else:
             cur = getattr(hip, k)
             if isinstance(cur, tuple):

@@ -18,8 +18,8 @@ net = hrnet.HRNetPose(48, 17, None, use_graph=False)
 hip = net.hip
 for kv in [q for q in args.spec.split(',') if q]:
     k, _, val = kv.partition('=')
-    if k == 'b96_tile':
-        hip.b96_tile = tuple(int(q) for q in val.split('x')); continue
+    if k in ('b96_tile', 'b48_tile'):
+        setattr(hip, k, tuple(int(q) for q in val.split('x'))); continue
     cur = getattr(hip, k)
     setattr(hip, k, tuple(int(c) for c in val) if isinstance(cur, tuple) else (int(val) if cur is None else type(cur)(int(val))))
 x = net.input_buffer(args.n); x.copy_(torch.randn(x.shape, device=dev).to(x.dtype)); x[:, 3:] = 0

@@ -9,7 +9,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append(dict(name=r['Kernel_Name'], s=int(r['Start_Timestamp']), e=int(r['End_Timestamp']), q=r.get('Queue_Id', ''), wg=wg,
                      lds=int(r.get('LDS_Block_Size', 0) or 0), vgpr=int(r.get('VGPR_Count', 0) or 0) + int(r.get('Accum_VGPR_Count', 0) or 0)))
 rows.sort(key=lambda r: r['s'])
-stem = [i for i, r in enumerate(rows) if 'k_conv_stem' in r['name']]
+stem = [i for i, r in enumerate(rows) if 'k_stem_fused' in r['name'] or 'k_conv_stem' in r['name']]
 a = stem[-2]; b = stem[-1]                       # the second-to-last replay: complete
 ks = rows[a:b]
 t0 = ks[0]['s']; t1 = max(k['e'] for k in ks)

@@ -23,8 +23,8 @@ FAMS=(
  "k_conv_gs_3x3s2_64to64_192x144|--shape 192,144,64,64,3,2 --res 0"
  "k_conv_gs_1x1_96to48_48x36|--shape 48,36,96,48,1,1 --res 0"
  "k_conv_gs64_1x1_384to336_12x9|--shape 12,9,384,336,1,1 --res 0"
- "k_pw2_bottleneck_tail_96x72|--shape 96,72,64,256,1,1 --tail 1"
- "k_pw1_64to64_96x72|--shape 96,72,64,64,1,1 --tail 2"
+ "k_bneck_3x3_tail_96x72|--shape 96,72,64,256,1,1 --tail 3"
+ "k_stem_fused_384x288|--shape 96,72,8,64,3,2 --tail 4"
 )
 for F in "${FAMS[@]}"; do
   NAME=${F%%|*}; ARGS=${F#*|}
@@ -43,7 +43,7 @@ for d in sorted(glob.glob('$OUT/*/')):
     for f in sorted(glob.glob(d+'p*/*/*counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             k=r['Kernel_Name']
-            if 'k_conv' not in k and 'k_bblock' not in k and 'k_pw' not in k: continue
+            if 'k_conv' not in k and 'k_bblock' not in k and 'k_pw' not in k and 'k_bneck' not in k and 'k_stem_fused' not in k: continue
             tot.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
     c={k:(sum(v[1:])/len(v[1:]) if len(v)>1 else v[0]) for k,v in tot.items()}
     if not c: continue
