@@ -653,6 +653,7 @@ class HipHRNet(ConvEngine):
                                 # 96-channel branch on the streamed-weights fused block (k_bblock2_96) -- csrc/pam_block2.hip
     c96_slab = 48               # 96 -> 96 layers that are NOT fused: k_conv3x3s with 48-channel slabs (0 = k_conv3x3)
     stamp = None                # diagnostics (tools/fwd_stamps.py): callable(tag) issued on the current stream at points of the schedule
+    knock_up = 0                # diagnostics: 1 = the coarsest branch's merged 1x1 up-convolution is not issued (its output stays uninitialised)
     knock_out = 0               # diagnostics: bit b = skip the BasicBlocks of branch b (what a free branch would be worth: tools/ab_flags.py)
 
     def _st(self, tag):
@@ -696,7 +697,10 @@ class HipHRNet(ConvEngine):
                     heads = {i: y[:, off:off + c] for i, off, c, _ in mg['parts']}
                 mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up) else None
                 if mu is not None:                                    # all 1x1 up-convolutions from this branch in one launch
-                    y = self.conv(mu['op'], x)
+                    if self.knock_up and b == len(mod['branches']) - 1:   # diagnostics: what the last finisher's tail is worth
+                        y = self._new(x.shape[0], mu['op'].cout, x.shape[2], x.shape[3], x.device)
+                    else:
+                        y = self.conv(mu['op'], x)
                     for i, off, c, sh in mu['parts']:
                         terms[i][b] = (y[:, off:off + c], sh)
                 for i, row in enumerate(fuse):
