@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void k_bblock2_48(BB2Args a) {
 constexpr int B96_NW = 8;                  // waves per workgroup (two per SIMD)
 constexpr int B96_NS = 27;                 // k-steps per convolution
 constexpr int B96_KIMG = 96 * 64;          // one k-step's weight image
-// M tiles per wave (conv1, conv2) are template parameters: <5, 4> takes items of up to 12 x 36 positions, <3, 2> half-size items
+// M tiles per wave (conv1, conv2) are template parameters: <3, 2> is instantiated (items of up to 6 x 36 positions; a <5, 4> form for 12 x 36 spilled and lost),
 constexpr int B96_TST = B96_NW * 16 * 64;  // byte distance between a wave's consecutive M tiles inside a chunk image (tile = wave + 4 i)
 constexpr int B96_XSP_MAX = 640;           // X slots per chunk image at most: 10 DMA pieces (16 slots x 64 B) per chunk and loader wave (waves 4-7)
 
@@ -551,9 +551,11 @@ __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
 }
 
 // instantiated (M tiles per wave for conv1, conv2) pairs, smallest first
-static const int kB96Inst[2][2] = {{3, 2}, {5, 4}};
+// one pair: the <5, 4> instantiation (twice the tile, for more than 32 crops) spilled 30 VGPRs and lost to 6 x 36 tiles in two rounds
+// (40 crops -1.4 %, 60 crops -0.3 % without it)
+static const int kB96Inst[1][2] = {{3, 2}};
 int b96_inst(int s1, int s2) {
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 1; ++k)
         if (s1 <= 16 * B96_NW * kB96Inst[k][0] && s2 <= 16 * B96_NW * kB96Inst[k][1]) return k;
     return -1;
 }
@@ -633,19 +635,18 @@ static int launch_bb96(void* stream, const void* in, const void* wpack, void* ou
     a.inv_pwx = 1.0f / (float)(a.TC + 4); a.inv_pwi = 1.0f / (float)(a.TC + 2);
     // junk M tiles of conv1 read up to 2 rows + 2 slots past the last real slot of a chunk image: keep that inside the allocation
     // half-size items with room for it: a 12-slot ring and one barrier per four k-steps
-    const int kpb = (inst == 0 && a.xsp <= 64 * 7) ? 4 : 2;          // 3 x 448 x 64 + 1 KB + 72 KB fits 160 KB
+    const int kpb = a.xsp <= 64 * 7 ? 4 : 2;          // 3 x 448 x 64 + 1 KB + 72 KB fits 160 KB
     size_t lds = (size_t)3 * a.xsp * 64 + 1024 + (size_t)3 * kpb * B96_KIMG;
     const size_t reach = (size_t)2 * a.xsp * 64 + (size_t)(16 * B96_NW * kB96Inst[inst][0] + 2 * (a.TC + 4) + 3) * 64;
     if (reach > lds) lds = reach;
     if (lds > 160 * 1024) return PAM_E_ARG;
-    if (!pam_max_dynamic_lds((const void*)k_bblock2_96<5, 4, 2, 10>, 160 * 1024) || !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 2, 10>, 160 * 1024) ||
+    if (!pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 2, 10>, 160 * 1024) ||
         !pam_max_dynamic_lds((const void*)k_bblock2_96<3, 2, 4, 7>, 160 * 1024)) return PAM_E_HIP;
 #ifdef PAM_DIAG
     a.stamps = g_bb2_stamps;
 #endif
-    if (inst == 0 && kpb == 4) pam_launch(k_bblock2_96<3, 2, 4, 7>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
-    else if (inst == 0) pam_launch(k_bblock2_96<3, 2, 2, 10>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
-    else pam_launch(k_bblock2_96<5, 4, 2, 10>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    if (kpb == 4) pam_launch(k_bblock2_96<3, 2, 4, 7>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
+    else pam_launch(k_bblock2_96<3, 2, 2, 10>, dim3(a.nitems), dim3(64 * B96_NW), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 

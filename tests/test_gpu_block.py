@@ -83,7 +83,12 @@ def test_block2_tile_choice_and_limits(eng):
     assert eng.lib.pam_basic_block2_tile(48, 20, 96, 72, t) == 0
     tr, tc = int(t[0]), int(t[1])
     assert 20 * -(-96 // tr) * -(-72 // tc) <= 256 and (tr + 4) * (tc + 4) <= 800       # one round of workgroups at 20 crops
-    assert eng.lib.pam_basic_block2_tile(96, 20, 48, 36, t) == 0 and (int(t[0]) + 4) * (int(t[1]) + 4) <= 640      # 96 channels: weights streamed
+    assert eng.lib.pam_basic_block2_tile(96, 20, 48, 36, t) == 0 and (int(t[0]) + 2) * (int(t[1]) + 4) <= 384      # 96 channels: weights streamed, 3 M tiles per wave
+    x96 = torch.zeros((1, 96, 48, 36), dtype=torch.bfloat16, device=eng.device).contiguous(memory_format=torch.channels_last)
+    w96 = torch.zeros(1024 + 2 * 27 * 96 * 64, dtype=torch.uint8, device=eng.device)
+    rc = eng.lib.pam_basic_block2_nhwc_bf16(C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream), C.c_void_p(x96.data_ptr()), C.c_void_p(w96.data_ptr()),
+                                            C.c_void_p(torch.empty_like(x96).data_ptr()), 1, 48, 36, 96, 12, 36)
+    assert rc != 0                                                                         # a 12 x 36 item needs the instantiation that was dropped
     assert eng.lib.pam_basic_block2_tile(192, 20, 24, 18, t) != 0
     x = torch.zeros((1, 48, 8, 8), dtype=torch.bfloat16, device=eng.device).contiguous(memory_format=torch.channels_last)
     y = torch.empty_like(x)
@@ -98,11 +103,12 @@ def test_block2_tile_choice_and_limits(eng):
 CASES96 = [
     # n, h, w, tile
     (2, 48, 36, None),
-    (20, 48, 36, None),          # the bench workload: 12 x 36 tiles, 80 items
-    (20, 48, 36, (12, 18)),
+    (20, 48, 36, None),          # the bench workload: 6 x 36 tiles, 160 items
+    (20, 48, 36, (4, 36)),
     (3, 48, 36, (6, 36)),
-    (2, 27, 36, (12, 36)),       # ragged last tile row
-    (2, 48, 34, (12, 18)),       # ragged last tile column
+    (2, 27, 36, (6, 36)),        # ragged last tile row
+    (2, 48, 34, (6, 18)),        # ragged last tile column
+    (40, 48, 36, None),          # two frames per replay: 320 items, two rounds of workgroups
     (2, 32, 24, None),           # 256 x 192 crops
     (3, 7, 5, None),             # tiny image
     (2, 21, 29, (7, 11)),
