@@ -255,7 +255,7 @@ int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int n_terms, c
  *   of 8 bf16]: row j*16 + q = output channel 8*(q >> 2) + 4*j + (q & 3) for j < 2 and 32 + 4*(q >> 2) + (q & 3) for j = 2, and
  *   physical piece p of row R holds K elements 8*(p ^ s) .. + 7 of the k-step with s = (0,2,3,1)[(R%16) >> 2] (LDS bank swizzle).
  *   Results are bit-identical to two pam_conv2d_nhwc_bf16 calls (same K order per output element).
- * C = 96 (k_bblock2_96<3,2> / <5,4>): the input tile resident (chunk-major, 3 x 32 channels), the weights of both convolutions
+ * C = 96 (k_bblock2_96<3,2>): the input tile resident (chunk-major, 3 x 32 channels), the weights of both convolutions
  *   streamed through a ring of six k-step images.  Limits: (rows + 4)(cols + 4) <= 640, (rows + 2)(cols + 4) <= 640, rows (cols + 2)
  *   <= 512 (half of the latter two for the small instantiation, which the picker prefers while it fills the chip).
  *   wpack (1 024 + 331 776 bytes): [float32 bias 96 + 96, padded to 1 KiB][54 k-step images of [96 rows][64 bytes]] in the order (conv,
