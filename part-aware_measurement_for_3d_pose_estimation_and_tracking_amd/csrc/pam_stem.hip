@@ -9,12 +9,12 @@
 //
 // LDS: [W2 72 KB][c1 buffer 0: 17 rows x 20 slots x 128 B = 42.5 KB][c1 buffer 1][biases 768 B] = 157.8 KB.
 // Work item = an 8 x 8 tile of x0; persistent workgroups, one per CU, eight waves in two roles (one wave of each per SIMD):
-//   producers (waves 4-7): conv1 on the 17 x 17 positions of c1 the tile's windows touch (289 positions = 19 wave tiles of 16; 13 %
+//   producers (waves 0-3): conv1 on the 17 x 17 positions of c1 the tile's windows touch (289 positions = 19 wave tiles of 16; 13 %
 //      recomputed in the halo).  As in k_conv_stem one MFMA covers a tap row (3 taps x 8 channels = 24 <= 32), the B fragment is the
 //      lane's 16-byte input pixel straight from global memory -- two register sets, item k + 1's pixels requested before item k is
 //      computed -- and the 12 weight fragments stay in registers.  The result (zero outside c1: conv2's padding) goes to one of TWO
 //      c1 buffers in LDS, 128 B per position.
-//   consumers (waves 0-3): conv2 from the other buffer: wave w owns x0 rows 2 w, 2 w + 1 of the tile (16 pixels), 4 N tiles, K = 9
+//   consumers (waves 4-7): conv2 from the other buffer: wave w owns x0 rows 2 w, 2 w + 1 of the tile (16 pixels), 4 N tiles, K = 9
 //      taps x 64 channels = 18 k-steps.  c1's columns are stored by parity (even columns, then odd ones, rows 20 slots apart) so that
 //      the 16 pixels of a stride-2 window read 2 x 8 CONSECUTIVE slots: with the usual piece swizzle (piece ^ (slot >> 1)) every
 //      fragment read is conflict-free.  conv2's weights (72 KB, [tap][64 rows][128 B], pieces swizzled the same way) are resident in
@@ -22,7 +22,7 @@
 //      -- AND the B fragments of the pointwise product: conv2's weight rows are permuted so that lane group g ends with channels
 //      32 h + 8 g .. + 7 (h = 0, 1), which is the natural K order of k_pw1; its 8 weight fragments sit in registers.
 //   One barrier per item: the producers have filled buffer k & 1 while the consumers emptied the other one.
-// Measured at 20 crops (tools/bench_stem.py, knock-out builds): 31 us against 70 for the three launches; the consumers alone 18, the
+// Measured at 20 crops (tools/bench_stem.py, knock-out builds): 28 us against 70 for the three launches; the consumers alone 18, the
 // producers alone 22 of which 16 are the input loads (5.6 without them; contiguous addresses instead of the stride-2 pattern: 17).
 // Same operand order per output element as the three kernels it replaces: results are bit-identical to theirs.
 #include <hip/hip_runtime.h>
@@ -91,12 +91,14 @@ __global__ __launch_bounds__(512, 1) void k_stem_fused(StemFArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                     // weights and biases are in LDS
 
-    // Iteration k: the producer waves (4-7) compute c1 of item k into buffer k & 1 while the consumer waves (0-3) run conv2 + the
+    // Iteration k: the producer waves (0-3) compute c1 of item k into buffer k & 1 while the consumer waves (4-7) run conv2 + the
     // pointwise product of item k - 1 out of buffer (k - 1) & 1; one barrier per iteration.  One wave of each kind per SIMD: the
     // consumer's LDS reads and MFMAs beside the producer's global loads, 12-MFMA bursts, conversions and LDS writes.
-    if (wave >= 4) {
+    // producers = waves 0-3, consumers = waves 4-7 (the other way round: 31.9 -> 29.8 us at 20 crops)
+    const int prod = wave < 4, lw_ = wave, cw = wave - 4;
+    if (prod) {
         // ================================================ producers: conv1 -> LDS ===============================================
-        const int lw = wave - 4;
+        const int lw = lw_;
         const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)((size_t)a.N * a.H * a.W * 16), 0x00020000);
         bf16x8 wf1[4][3];                               // A fragments [N tile][tap row]
 #pragma unroll
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(512, 1) void k_stem_fused(StemFArgs a) {
             unsigned off[MAXT1][3];
 #pragma unroll
             for (int i = 0; i < MAXT1; ++i) {
-                const int t = lw + 4 * i;
+                const int t = lw * MAXT1 + i;            // consecutive wave tiles per wave (interleaved over the waves: +1.7 us)
                 const int P = 16 * t + p, ry = (P * 241) >> 12, rx = P - 17 * ry;          // P / 17, exact below 4096
                 const int cy = 2 * R0 - 1 + ry, cx = 2 * C0 - 1 + rx;
                 const bool ok1 = (P < NPOS) & ((unsigned)cy < (unsigned)a.H1) & ((unsigned)cx < (unsigned)a.W1);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(512, 1) void k_stem_fused(StemFArgs a) {
             char* const region = smem + W2B + (k & 1) * REGB;
 #pragma unroll
             for (int i = 0; i < MAXT1; ++i) {
-                const int t = lw + 4 * i;
+                const int t = lw * MAXT1 + i;            // consecutive wave tiles per wave (interleaved over the waves: +1.7 us)
                 if (t < NPT1) {
                     f32x4 acc[4];
 #pragma unroll
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(512, 1) void k_stem_fused(StemFArgs a) {
     // fragment addresses: pixel (2 wave + (p >> 3), p & 7) of the tile
     unsigned boff[9];
     {
-        const int base = (2 * (2 * wave + (p >> 3))) * RP + (p & 7);
+        const int base = (2 * (2 * cw + (p >> 3))) * RP + (p & 7);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void k_stem_fused(StemFArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     accp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfp[h][j]), __builtin_bit_cast(bf16x8_t, xf[h]), accp[j], 0, 0, 0);
-            const int oy = R0 + 2 * wave + (p >> 3), ox = C0 + (p & 7);
+            const int oy = R0 + 2 * cw + (p >> 3), ox = C0 + (p & 7);
             if (oy < a.H2 && ox < a.W2) {
                 const size_t pix = ((size_t)n * a.H2 + oy) * a.W2 + ox;
                 char* xo = (char*)a.x0 + pix * 128 + g * 16;
