@@ -14,7 +14,8 @@
 //   2. the convolution: wave w owns rows (w & 3) + 8 (w >> 2) and that + 4 of the tile (16 pixels; two runs of 8 consecutive slots
 //      40 slots apart: with the piece swizzle every fragment read is conflict-free), 4 N tiles, 18 k-steps in k_conv3x3s's order
 //      (channels 0-31 of all nine taps, then channels 32-63);
-//   3. the tail exactly as k_pw2 with one 16-pixel tile per wave: per 64-channel slab 8 MFMAs, + residual (requested a slab ahead),
+//   3. the tail exactly as k_pw2 with one 16-pixel tile per wave: per 64-channel slab 8 MFMAs, + residual (requested a slab ahead; all
+//      four slabs requested in front of the convolution: 41 instead of 37 us),
 //      ReLU, one bf16 rounding, 2 x 16-byte stores, and the slab's 8 MFMAs of the next block's conv1.
 // Same operand order per output element as the two kernels it replaces: results are bit-identical to theirs.
 #include <hip/hip_runtime.h>
