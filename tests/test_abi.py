@@ -147,3 +147,30 @@ def test_algorithmic_work_is_executor_independent_and_launch_counts_follow_the_c
     assert a['launches'] == 221 and b['launches'] == 253 and a['bytes_as_executed'] < b['bytes_as_executed']
     assert a['bytes'] < a['bytes_as_executed']                       # the deep branches' block interiors are traffic only as executed
     assert hrnet.algorithmic_work(40)['bytes'] > 1.9 * a['bytes']    # activations scale with the crops, the weights do not
+
+
+def test_conv64_image_follows_the_layout_pam_h_documents():
+    """The [9 taps][64 rows][64 K] weight image of the fused stem / Bottleneck kernels (include/pam.h, pam_stem_fused_nhwc_bf16): row
+    16 j + q of a tap = output channel 32 (j >> 1) + 8 (q >> 2) + 4 (j & 1) + (q & 3); the row's 16-byte piece at position p holds input
+    channels 8 c .. 8 c + 7 with c = p ^ ((q >> 1) & 7).  Checked element by element against a weight tensor whose every entry encodes its
+    own index (host logic only: packs on the CPU)."""
+    import torch
+    import torch.nn as nn
+    from pam import hrnet_hip
+    conv = nn.Conv2d(64, 64, 3, 1, 1, bias=True)
+    co, ci, ky, kx = torch.meshgrid(torch.arange(64), torch.arange(64), torch.arange(3), torch.arange(3), indexing='ij')
+    with torch.no_grad():
+        conv.weight.copy_((co * 64 + ci).float() + (ky * 3 + kx).float() / 16.0)     # exact in bf16? no: compare after the same rounding
+    img = hrnet_hip.conv64_image(conv, torch.device('cpu')).float().reshape(9, 64, 8, 8)
+    want = conv.weight.detach().to(torch.bfloat16).float()
+    for tap in (0, 4, 8):
+        for row in (0, 5, 17, 38, 63):
+            j, q = row // 16, row % 16
+            ch = 32 * (j >> 1) + 8 * (q >> 2) + 4 * (j & 1) + (q & 3)
+            for p in range(8):
+                c = p ^ ((q >> 1) & 7)
+                assert torch.equal(img[tap, row, p], want[ch, 8 * c:8 * c + 8, tap // 3, tap % 3]), (tap, row, p)
+    # every output channel appears exactly once per tap
+    rows = torch.arange(64)
+    chs = 32 * ((rows // 16) >> 1) + 8 * ((rows % 16) >> 2) + 4 * ((rows // 16) & 1) + (rows % 16 & 3)
+    assert sorted(chs.tolist()) == list(range(64))
