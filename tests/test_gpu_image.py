@@ -504,14 +504,15 @@ def test_configuration_follows_the_crop_count_and_stays_consistent():
     from pam import hrnet, hrnet_hip
     a = hrnet.HRNetPose(48, 17, None, use_graph=True)
     b = hrnet.HRNetPose(48, 17, None, use_graph=True, autotune=True)
-    x = a.input_buffer(3)
+    x = a.input_buffer(9)
     x.copy_(torch.randn(x.shape, device=x.device).to(x.dtype)); x[:, 3:] = 0
     ref = a.features(x).float().clone()
     y1 = b.features(x).clone()
     y2 = b.features(x).clone()
     y3 = b.features(x, slot=1).clone()
     torch.cuda.synchronize()
-    assert b.tuned[3]['choice'] == 'resident48_streamed96' and a.tuned[3]['choice'] == hrnet_hip.HipHRNet.config_name == 'fused48_fused96'
+    assert b.tuned[9]['choice'] == 'resident48_streamed96' and a.tuned[9]['choice'] == hrnet_hip.HipHRNet.config_name == 'fused48_fused96'
+    assert b.config_for(4) == 'fused48_fused96' and b.config_for(16) == 'fused48_fused96'
     assert torch.equal(y1, y2) and torch.equal(y1, y3)
     assert float((y1.float() - ref).norm() / ref.norm()) < 1e-2
     x20 = b.input_buffer(20)
