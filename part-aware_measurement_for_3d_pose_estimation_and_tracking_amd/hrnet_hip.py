@@ -653,6 +653,7 @@ class HipHRNet(ConvEngine):
                                 # 96-channel branch on the streamed-weights fused block (k_bblock2_96) -- csrc/pam_block2.hip
     c96_slab = 48               # 96 -> 96 layers that are NOT fused: k_conv3x3s with 48-channel slabs (0 = k_conv3x3)
     stamp = None                # diagnostics (tools/fwd_stamps.py): callable(tag) issued on the current stream at points of the schedule
+    knock_conv2 = 0             # diagnostics: 1 = the second convolution of every un-fused BasicBlock is not issued
     knock_up = 0                # diagnostics: 1 = the coarsest branch's merged 1x1 up-convolution is not issued (its output stays uninitialised)
     knock_out = 0               # diagnostics: bit b = skip the BasicBlocks of branch b (what a free branch would be worth: tools/ab_flags.py)
 
@@ -671,6 +672,9 @@ class HipHRNet(ConvEngine):
             return x
         for c1, c2 in blocks:
             y = self.conv(c1, x, relu=True)
+            if self.knock_conv2:                                      # diagnostics: half the launches AND half the work of the un-fused branches
+                x = y
+                continue
             x = self.conv(c2, y, res=x, relu=True)
         return x
 
