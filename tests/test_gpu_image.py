@@ -438,6 +438,27 @@ def test_replay_equals_eager_forward_in_every_configuration(n):
     assert float((v[0] - v[1]).norm() / v[0].norm()) < 1e-2
 
 
+@pytest.mark.parametrize('n', [3, 20])
+def test_fused_head_is_bit_identical_to_the_launches_it_replaces(n):
+    """k_stem_fused (stem + first conv1) and k_bneck (3x3 + pointwise tail of every layer1 Bottleneck) keep the operand order of the
+    kernels they replace: the whole network's features are bit-identical with each of them switched off (eager forwards of one network
+    object, flags toggled)."""
+    from pam import hrnet
+    a = hrnet.HRNetPose(48, 17, None, use_graph=False)
+    x = a.input_buffer(n)
+    x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(40 + n)).to(x.device).to(x.dtype)); x[:, 3:] = 0
+    assert a.hip.fuse_stem and a.hip.fuse_bneck and a.hip.fuse_bneck0
+    ref = a.features(x).clone()
+    for flags in (dict(fuse_stem=False), dict(fuse_bneck=False), dict(fuse_bneck0=False), dict(fuse_stem=False, fuse_bneck=False)):
+        for k, v in flags.items():
+            setattr(a.hip, k, v)
+        y = a.features(x).clone()
+        torch.cuda.synchronize()
+        for k in flags:
+            setattr(a.hip, k, True)
+        assert torch.equal(ref, y), flags
+
+
 def test_full_pipeline_panoptic31_sized_frame():
     """Config #5's frames on ONE GPU through the drop-in surface: 31 HD views x 7 persons = 217 crops -> PersonPoseDetect (eleven batches
     of 20 through the replay, the last padded) -> PersonTrack_Project3DPose on the device-resident keypoints (k_frame<1024>: more than 8
