@@ -70,6 +70,8 @@ class PackedConv(object):
             m.bias.copy_(torch.cat([(c.bias.detach().float() if c.bias is not None else torch.zeros(c.out_channels)) for c in convs]))
         return PackedConv(m, device)
 
+    layout_lib = None           # tools/ab_conv_defs.py: a build variant whose layout functions decide the image (default: the library)
+
     def image(self, h, w, classic=False, c96_slab=0):
         """Weight image of this layer at input h x w for the rows-in-LDS kernels (layouts: include/pam.h): the classic per-chunk image
         [cout/BN][cin/CK][BN][pitch/2] (row = 9 taps x CK channels + pad), or -- where pam_conv3x3_layout() says so and the caller does
@@ -78,7 +80,7 @@ class PackedConv(object):
             return self._stem
         if self._w_ohwi is None:
             return None
-        lib = _lib.load()
+        lib = self.layout_lib or _lib.load()
         bn_s = 0 if classic else lib.pam_conv3x3_layout_ex(int(h), int(w), self.cin, self.cout, int(c96_slab))     # > 0: streamed kernel, with this slab width
         streamed = bn_s > 0
         bn = bn_s if streamed else lib.pam_conv3x3_slab(int(h), int(w), self.cin, self.cout)

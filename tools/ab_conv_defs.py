@@ -50,7 +50,7 @@ for (h, w, cin, cout, k, s, with_res) in LAYERS:
     res = torch.randn((args.n, cout, h, w)).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last) if with_res else None
     graphs = []
     for lib in (base, Both(var, base)):
-        e.lib = lib
+        e.lib = lib; op.layout_lib = lib
         graphs.append(timeit(lambda: e.conv(op, x, res=res, relu=True), args.iters))
     t = [[], []]
     for r in range(7):
