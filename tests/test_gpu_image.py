@@ -438,6 +438,28 @@ def test_replay_equals_eager_forward_in_every_configuration(n):
     assert float((v[0] - v[1]).norm() / v[0].norm()) < 1e-2
 
 
+def test_bf16_stack_vs_fp32_at_the_256x192_resolution():
+    """The reference's other pose input size (256 x 192 crops -> 64 x 48 maps, every branch a different tiling of the fused kernels):
+    heat-maps against the same folded weights in fp32, replay against eager, as at 384 x 288."""
+    from pam import hrnet
+    net = hrnet.HRNetPose(48, 17, None, resolution=(256, 192), use_graph=True)
+    dev = net.device
+    ref = hrnet.fold_batchnorm(hrnet.init_random(hrnet.PoseHighResolutionNet(), seed=0)).to(dev).eval()
+    g = torch.Generator().manual_seed(4)
+    x32 = torch.randn((3, 3, 256, 192), generator=g).to(dev)
+    x8 = torch.cat([x32, torch.zeros((3, 5, 256, 192), device=dev)], dim=1).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        h32 = ref(x32.to(torch.bfloat16).float())
+        hb = net.heatmaps(x8).clone()
+        eager = hrnet.HRNetPose(48, 17, None, resolution=(256, 192), use_graph=False)
+        he = eager.heatmaps(x8)
+    torch.cuda.synchronize()
+    assert tuple(hb.shape) == (3, 17, 64, 48)
+    assert torch.equal(hb, he)
+    rel = ((hb.float() - h32).norm() / h32.norm()).item()
+    assert rel < 0.03, rel
+
+
 @pytest.mark.parametrize('n', [3, 20])
 def test_fused_head_is_bit_identical_to_the_launches_it_replaces(n):
     """k_stem_fused (stem + first conv1) and k_bneck (3x3 + pointwise tail of every layer1 Bottleneck) keep the operand order of the
