@@ -223,10 +223,10 @@ int pam_conv3x3_slab(int H, int W, int Cin, int Cout);
  * 256 -> 48); the streamed kernel takes activation codes 0 / 1 only, so a layer with a Darknet code (relu > 1) must be packed in the
  * classic layout and called with tile_cfg == -2 (tile_cfg == -1 with a streamed image and relu > 1 returns PAM_E_ARG). */
 int pam_conv3x3_layout(int H, int W, int Cin, int Cout);
-/* the same with the 96 -> 96 layers' choice stated: c96_slab 0 = they stay on k_conv3x3 (the answer above), 48 / 96 = streamed with
- * slabs of that many output channels (96: the input patch is fetched once per tile instead of once per slab).  The caller packs the
- * image for the slab returned and says so at the launch: tile_cfg -5 (slab 48) / -6 (slab 96) of pam_conv2d_nhwc_bf16_ex, which
- * otherwise behave like -3 (streamed layout stated; -4 = classic layout stated). */
+/* the same with the 96 -> 96 layers' choice stated: c96_slab 0 = they stay on k_conv3x3 (the answer above), 48 = streamed with slabs
+ * of 48 output channels (the only streamed slab width instantiated for these layers; any other value answers as 0).  The caller packs
+ * the image for the slab returned and says so at the launch: tile_cfg -5 of pam_conv2d_nhwc_bf16_ex, which otherwise behaves like -3
+ * (streamed layout stated; -4 = classic layout stated). */
 int pam_conv3x3_layout_ex(int H, int W, int Cin, int Cout, int c96_slab);
 /* which kernel the calling thread's last pam_conv2d_nhwc_bf16[_ex] call launched (labels for per-kernel profiles) */
 #define PAM_CONV_KERNEL_IGEMM 0   /* k_conv_igemm */
@@ -256,8 +256,8 @@ int pam_upsample_add_nhwc_bf16_ex(void* stream, const void* base, int n_terms, c
  *   physical piece p of row R holds K elements 8*(p ^ s) .. + 7 of the k-step with s = (0,2,3,1)[(R%16) >> 2] (LDS bank swizzle).
  *   Results are bit-identical to two pam_conv2d_nhwc_bf16 calls (same K order per output element).
  * C = 96 (k_bblock2_96<3,2>): the input tile resident (chunk-major, 3 x 32 channels), the weights of both convolutions
- *   streamed through a ring of six k-step images.  Limits: (rows + 4)(cols + 4) <= 640, (rows + 2)(cols + 4) <= 640, rows (cols + 2)
- *   <= 512 (half of the latter two for the small instantiation, which the picker prefers while it fills the chip).
+ *   streamed through a ring of six k-step images (twelve while the tile's (rows + 4)(cols + 4) slots, rounded up to 16, stay <= 448).
+ *   Limits of the one instantiation shipped (<3,2>): (rows + 4)(cols + 4) <= 640, (rows + 2)(cols + 4) <= 384, rows (cols + 2) <= 256.
  *   wpack (1 024 + 331 776 bytes): [float32 bias 96 + 96, padded to 1 KiB][54 k-step images of [96 rows][64 bytes]] in the order (conv,
  *   chunk of 32 input channels, tap); row j*16 + q = output channel 24*(q >> 2) + 4*j + (q & 3); physical 16-byte piece p of row r
  *   holds the chunk's input channels 8*(p ^ ((r >> 1) & 2)) .. + 7.  The residual enters the sum before the products (as in the

@@ -305,16 +305,15 @@ class HRNetPose(object):
         self.head_w = self.head.weight.detach().reshape(int(nof_joints), -1).contiguous()     # [17][48] for k_head
         self.head_b = self.head.bias.detach().contiguous()
         model.final_layer = nn.Identity()
+        # the conv stack = the hand-written MFMA kernels of csrc/ (hrnet_hip.HipHRNet); there is no other backend in the product: the
+        # PyTorch-ROCm form of the same folded module that the tests compare against lives in tests/torch_ref.py
+        if backend != 'hip':
+            raise ValueError("HRNetPose has one conv backend, 'hip' (got %r)" % (backend,))
         self.backend = backend
-        self.in_channels = 3
-        if backend == 'hip':                                            # hand-written MFMA conv kernels (csrc/pam_conv.hip)
-            from .hrnet_hip import HipHRNet
-            self.hip = HipHRNet(model, self.device)
-            self.in_channels = 8
-            self.model = None
-        else:                                                           # 'miopen': PyTorch-ROCm convs (reference for tests)
-            assert backend == 'miopen', backend
-            self.model = model.to(self.device).to(dtype).to(memory_format=torch.channels_last).eval()
+        from .hrnet_hip import HipHRNet
+        self.hip = HipHRNet(model, self.device)
+        self.in_channels = 8
+        self.model = None
         self.use_graph = use_graph
         # predict() pads a batch to the next multiple of graph_bucket crops (repeating its last box; the padded rows are not
         # decoded): a sequence whose person count wanders then replays a handful of captured graphs instead of capturing one
@@ -323,7 +322,7 @@ class HRNetPose(object):
         self._graphs = {}
         # autotune: the executor configuration follows the crop count (config_for); off = one configuration for every count (results of
         # different configurations differ in the last bf16 bits, and a test that compares an eager forward with a replay needs both in ONE)
-        self.autotune = bool(autotune) and backend == 'hip' and use_graph
+        self.autotune = bool(autotune) and use_graph
         self.tuned = {}                                   # crop count -> {'choice': configuration name} of every replay captured so far
         self._kp_pinned = {}         # crop count -> two pinned host buffers for predict()'s keypoints
         self._meta_pinned = {}       # table size -> two pinned staging buffers for predict()'s per-call tables
@@ -338,9 +337,6 @@ class HRNetPose(object):
 
     # -- conv stack (PyTorch-ROCm; hipGraph replay per batch size) -------------------------------------------------
     def _forward(self, x, kind='heatmaps'):
-        if self.backend != 'hip':
-            f = self.model.features(x)
-            return f if kind == 'features' else self.head(f.float())
         f = self.hip.features(x)                                        # (N, 48, h, w) channels-last bf16
         if kind == 'features':
             return f
@@ -380,9 +376,8 @@ class HRNetPose(object):
                 return self._forward(x, kind)
         g = self._graphs.get((n, kind, slot))
         if g is None:
-            if self.backend == 'hip':
-                self.hip.apply_config(self.config_for(n))
-                self.hip.arena = self._arena_for(n, slot)
+            self.hip.apply_config(self.config_for(n))
+            self.hip.arena = self._arena_for(n, slot)
             other = self._graphs.get((n, 'features' if kind == 'heatmaps' else 'heatmaps', slot))
             static_in = other[1] if other is not None else torch.empty_like(x)     # one input buffer per batch size and slot
             static_in.copy_(x)
@@ -396,8 +391,7 @@ class HRNetPose(object):
                 graph = _lib.new_graph()
                 with torch.cuda.graph(graph, pool=self._pool_of(slot)):
                     static_out = self._forward(static_in, kind)
-            if self.backend == 'hip':
-                self.hip.arena = None
+            self.hip.arena = None
             g = (graph, static_in, static_out)
             self._graphs[(n, kind, slot)] = g
         graph, static_in, static_out = g
@@ -522,7 +516,7 @@ class HRNetPose(object):
         views, slots, boxes, frames, cnt = [], [], [], {}, [0] * V
         for v, persons in enumerate(person_bbox_list):
             for p in persons:
-                views.append(v); slots.append(cnt[v]); cnt[v] += 1; boxes.append(p['bbox'])
+                views.append(v); slots.append(cnt[v]); cnt[v] += 1; boxes.append(list(p['bbox']))     # copied: the dump is built lazily
                 if v not in frames:
                     d = p['data']
                     if not torch.is_tensor(d):
@@ -542,12 +536,18 @@ class HRNetPose(object):
         o_ptr = 6 * n + V + (V & 1)
         meta[o_ptr:].view(np.int64)[:] = [frames[v].data_ptr() if v in frames else 0 for v in range(V)]
         # staged through a pinned buffer of its own (two per size, alternating): the upload is asynchronous and the host goes on issuing
+        # (each buffer carries the event recorded behind its last upload: a host that runs more than two calls ahead of the GPU -- device
+        # frames, dumps dropped unread -- must not overwrite a table whose copy has not been issued to the device yet)
         stage = self._meta_pinned.setdefault(meta.size, [])
         if len(stage) < 2:
-            stage.append(torch.empty(meta.size, dtype=torch.int32).pin_memory())
+            stage.append([torch.empty(meta.size, dtype=torch.int32).pin_memory(), None])
         stage.reverse()
-        stage[0].numpy()[:] = meta
-        m = stage[0].to(self.device, non_blocking=True)
+        if stage[0][1] is not None:
+            stage[0][1].synchronize()
+        stage[0][0].numpy()[:] = meta
+        m = stage[0][0].to(self.device, non_blocking=True)
+        stage[0][1] = torch.cuda.Event()
+        stage[0][1].record(torch.cuda.current_stream(self.device))
         view_of, slot_of = m[:n], m[n:2 * n]
         bx = m[2 * n:6 * n].view(torch.float32).reshape(n, 4)
         n_det = m[6 * n:6 * n + V]
@@ -569,10 +569,7 @@ class HRNetPose(object):
                 vo = torch.cat([vo, vo[-1:].expand(mp - k)]); bb = torch.cat([bb, bb[-1:].expand(mp - k, 4)])
             x = self.input_buffer(mp)
             self.preprocess(ptrs, fh, fw, vo.contiguous(), bb.contiguous(), x)
-            if self.backend == 'hip':
-                self.head_decode(self.features(x), view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e], n=k)
-            else:
-                self.decode(self.heatmaps(x)[:k], view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e])
+            self.head_decode(self.features(x), view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e], n=k)
         if self.world > 1:
             from .distributed import gather_crop_keypoints
             kp = gather_crop_keypoints(kp[lo:hi].contiguous(), n, self.world, self.rank, self.group)
@@ -705,6 +702,16 @@ for _n in ('__getitem__', '__iter__', '__reversed__', '__contains__', '__eq__', 
            'insert', 'pop', 'remove', 'index', 'count', 'copy', 'sort', 'reverse', 'clear'):
     setattr(DumpResults, _n, _lazy(_n))
 del _n
+
+
+def _radd(self, other):
+    # `[] + dump`: list.__add__ of the LEFT operand is a C fast path that reads a list subclass's items directly (it would see the empty
+    # per-view lists); Python tries the right operand's __radd__ first when its type is a subclass of the left one's -- fill in here
+    self._materialise()
+    return list(other) + list(list.__iter__(self))
+
+
+DumpResults.__radd__ = _radd
 
 
 def measure_bf16_drift(net, n_crops=2, seed=2, checker_device='cpu'):

@@ -95,3 +95,13 @@ def test_pending_dump_survives_copy_pickle_and_json():
         d, kp, ev = _pending_dump()
         got = f(d)
         assert [len(v) for v in got] == [2, 1] and got[1][0]['bbox'] == [2, 2, 5, 5]
+
+
+def test_pending_dump_on_the_right_of_a_list_concatenation():
+    """`[] + dump`: list.__add__ of the LEFT operand reads a list subclass's items through a C fast path; DumpResults.__radd__ gets there first."""
+    d, kp, ev = _pending_dump()
+    got = [] + d
+    assert type(got) is list and [len(v) for v in got] == [2, 1] and got[0][1]['bbox'] == [1, 1, 5, 5] and ev.waited >= 1
+    d, kp, ev = _pending_dump()
+    got = [['x']] + d
+    assert got[0] == ['x'] and [len(v) for v in got[1:]] == [2, 1]

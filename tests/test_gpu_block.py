@@ -113,6 +113,10 @@ CASES96 = [
     (3, 7, 5, None),             # tiny image
     (2, 21, 29, (7, 11)),
     (28, 48, 36, None),
+    # (rows + 4)(cols + 4) in (448, 640]: the two-k-steps-per-barrier form with its six-slot ring (KPB = 2, NPW = 10) -- wider maps at
+    # other input resolutions reach it through the tile picker
+    (2, 40, 60, (4, 60)),        # 8 x 64 = 512 slots
+    (2, 6, 124, (1, 124)),       # 5 x 128 = 640 slots: the largest tile the kernel takes
 ]
 
 

@@ -10,7 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, default=20)
 ap.add_argument('--iters', type=int, default=10)
 ap.add_argument('--modes', default='graph')
-ap.add_argument('--backends', default='hip,miopen')
+ap.add_argument('--backends', default='hip')
 ap.add_argument('--no-branch-streams', action='store_true')
 ap.add_argument('--order', default='0,1,2,3')
 ap.add_argument('--config', default='', help='executor configuration (HipHRNet.CONFIGS); empty = the flags below'); ap.add_argument('--merge', type=int, default=2, help='0: no merged fuse convs, 1: strided chains only, 2: + up-convs')
