@@ -308,6 +308,35 @@ int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const void* x0, 
                                   const float* bias3, const void* w1_img, const float* bias1, void* out_x, void* out_y1,
                                   long long n_pixels, int tile_cfg);
 
+/* ---- round 5: the fuse layers of an HR module (row a1; hrnet.py:64-100 -- stands inside the absent HRNet backend behind
+ * /root/reference/src/ivclabpose.py:210): every output i of a module is ReLU(x_i + strided-convolution chains from the finer branches +
+ * up-sampled 1x1 convolutions of the coarser ones).
+ *
+ * pam_conv3x3s2_c48_nhwc_bf16 (csrc/pam_down.hip, k_down48): out = [ReLU on channels >= relu_from](conv3x3 stride 2 pad 1 (in) + bias
+ * [+ res]) for Cin = 48: the input patch of a tile of output positions resident in LDS (columns stored by parity), the output channels
+ * walked in 48-channel slabs whose weights are resident and double-buffered.  in: (N, H, W) pixels of in_cstride channels (the first 48
+ * are read: a channel slice of a wider tensor is fine); out / res: (N, Ho, Wo) pixels of out_cstride / res_cstride channels, Ho = (H - 1)
+ * / 2 + 1; Cout % 48 == 0.  wpack: Cout / 48 slab images of 43 008 bytes, slab s = output channels 48 s .. + 47 in the layout of ONE
+ * convolution of pam_basic_block2_nhwc_bf16's C = 48 image ([14 k-steps][48 rows][64 bytes], see there).  tile_rows / tile_cols <= 0 and
+ * slab_groups <= 0: the library's choice (pam_conv3x3s2_c48_tile writes {rows, cols, groups}); slab_groups = workgroups an item's slabs
+ * are spread over (divides Cout / 48).  Results are bit-identical to pam_conv2d_nhwc_bf16 (same K order per output element).
+ *
+ * pam_fuse_sum_nhwc_bf16 (csrc/pam_fuse.hip, k_fuse_sum): out = [ReLU](base + sum_t plain_t + sum_s nearest_up_{2^shift_s}(W_s . src_s +
+ * bias_s)): base / out / plain_t (N, H, W, C) NHWC bf16, C in {48, 96, 192} (plain_t may be channel slices: plain_cstrides, NULL = C);
+ * src_s (N, H >> shift_s, W >> shift_s, up_channels[s]) with ascending shifts, up_channels % 32 == 0, H and W multiples of 2^shift;
+ * up_wimg[s]: the 1x1 weights (C x up_channels[s]) as MFMA A fragments, bf16 [C / 16][up_channels / 32][64 lanes][8]: lane l of fragment
+ * (j, ks) holds W[16 j + (l & 15)][32 ks + 8 (l >> 4) .. + 7]; up_bias[s]: float32 [C] or NULL.  n_plain <= 2, 1 <= n_up <= 3.  The 1x1
+ * products are computed per tile of tile_a x tile_b pixels of the coarsest source (<= 0: the library's choice) and never reach HBM;
+ * sum order = base, plain terms, up terms (the order of pam_upsample_add_nhwc_bf16 with the terms in branch order).  Results are
+ * bit-identical to pam_conv2d_nhwc_bf16 (1x1) per source followed by pam_upsample_add_nhwc_bf16. */
+int pam_conv3x3s2_c48_tile(int N, int H, int W, int Cout, int32_t* out3);
+int pam_conv3x3s2_c48_nhwc_bf16(void* stream, const void* in, int in_cstride, const void* wpack, const float* bias, const void* res,
+                                int res_cstride, void* out, int out_cstride, int N, int H, int W, int Cout, int relu, int relu_from,
+                                int tile_rows, int tile_cols, int slab_groups);
+int pam_fuse_sum_nhwc_bf16(void* stream, const void* base, int n_plain, const void* const* plain, const int32_t* plain_cstrides, int n_up,
+                           const void* const* up_src, const int32_t* up_shifts, const int32_t* up_channels, const void* const* up_wimg,
+                           const float* const* up_bias, void* out, int N, int H, int W, int C, int relu, int tile_a, int tile_b);
+
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before
  * the cross-view match every rank contributes its views' keypoint records and receives everyone's: ONE all-gather per frame, enqueued on

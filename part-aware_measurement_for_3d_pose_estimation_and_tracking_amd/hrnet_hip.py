@@ -112,6 +112,49 @@ class PackedConv(object):
         return img
 
 
+def down48_image(op):
+    """Weight image of a 3x3 stride-2 convolution with 48 input channels for ``pam_conv3x3s2_c48_nhwc_bf16`` (csrc/pam_down.hip; layout:
+    include/pam.h): per 48-channel slab of the output [14 k-steps][48 rows][4 pieces][8] -- K = (tap, cin) flattened and zero-padded to
+    14 * 32, rows permuted and 16-byte pieces swizzled exactly as one convolution of PackedBlock's C = 48 image."""
+    assert op.cin == 48 and op.kh == 3 and op.kw == 3 and op.cout % 48 == 0
+    img = getattr(op, '_down48', None)
+    if img is None:
+        ns, nstep = op.cout // 48, 14
+        rows = torch.arange(48)
+        j, qq, r = rows // 16, (rows % 16) >> 2, rows & 3
+        chan = torch.where(j < 2, 8 * qq + 4 * j + r, 32 + 4 * qq + r)
+        src = torch.arange(4)[None, :] ^ torch.tensor([0, 2, 3, 1])[qq][:, None]
+        wk = torch.zeros((op.cout, nstep * 32), dtype=torch.float32)
+        wk[:, :432] = op.w[:, :432].float().cpu()                                           # [cout][k = tap * 48 + cin]
+        wk = wk.reshape(ns, 48, nstep, 4, 8)[:, chan]                                        # [slab][row][k-step][piece][8]
+        wk = torch.gather(wk, 3, src[None, :, None, :, None].expand(ns, 48, nstep, 4, 8)).permute(0, 2, 1, 3, 4)
+        img = op._down48 = wk.to(torch.bfloat16).to(op._device).contiguous()
+        assert img.numel() * 2 == ns * 43008
+    return img
+
+
+class PackedUp(object):
+    """The 1x1 convolutions into ONE output of an HR module's fuse layer, packed for ``pam_fuse_sum_nhwc_bf16`` (csrc/pam_fuse.hip):
+    per coarser source branch the weights as MFMA A fragments [C / 16][Cs / 32][64 lanes][8] (lane l of fragment (j, ks) holds
+    W[16 j + (l & 15)][32 ks + 8 (l >> 4) .. + 7]) and the float32 bias."""
+
+    def __init__(self, convs, shifts, device):
+        self.c = convs[0].weight.shape[0]
+        self.shifts, self.chans, self.wimg, self.bias = list(shifts), [], [], []
+        for cv in convs:
+            c, cs = cv.weight.shape[0], cv.weight.shape[1]
+            assert c == self.c and cv.weight.shape[2:] == (1, 1) and cs % 32 == 0 and c % 16 == 0
+            w = cv.weight.detach().float().reshape(c // 16, 16, cs // 32, 4, 8).permute(0, 2, 3, 1, 4)     # [j][ks][g][q][8]
+            self.wimg.append(w.reshape(c // 16, cs // 32, 64, 8).to(torch.bfloat16).to(device).contiguous())
+            self.bias.append((cv.bias.detach().float() if cv.bias is not None else torch.zeros(c)).to(device).contiguous())
+            self.chans.append(cs)
+        n = len(convs)
+        self.c_w = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in self.wimg])
+        self.c_b = (C.c_void_p * n)(*[C.c_void_p(t.data_ptr()) for t in self.bias])
+        self.c_sh = (C.c_int32 * n)(*self.shifts)
+        self.c_ch = (C.c_int32 * n)(*self.chans)
+
+
 class PackedBlock(object):
     """One BasicBlock (conv3x3 -> ReLU -> conv3x3 -> + x -> ReLU) of the 48- or 96-channel branch packed for
     ``pam_basic_block2_nhwc_bf16`` (csrc/pam_block2.hip; layouts: include/pam.h): ONE buffer ``wpack`` =
@@ -311,6 +354,9 @@ class ConvEngine(object):
         """relu: False/True, or 'linear' | 'relu' | 'leaky' (slope 0.1); res_after_act: out = act(conv + b) + res (Darknet shortcut).
         x may be a channel slice of a wider channels-last tensor; relu_from: the activation applies to channels >= relu_from."""
         n, cin, h, w = x.shape
+        if (self.down48 and op.stride == 2 and op.kh == 3 and op.kw == 3 and op.pad == 1 and op.cin == 48 and op.cout % 48 == 0 and
+                self.ACT[relu] <= 1 and not res_after_act and relu_from % 8 == 0):
+            return self.conv_down48(op, x, res=res, relu=bool(self.ACT[relu]), relu_from=relu_from)
         in_cs = cin if x.device.type == 'meta' else x.stride(3)          # channels between neighbouring pixels
         assert cin == op.cin and (x.device.type == 'meta' or (x.stride(1) == 1 and x.stride(2) == w * in_cs and x.stride(0) == h * w * in_cs)), (x.shape, op.cin)
         ho = (h + 2 * op.pad - op.kh) // op.stride + 1
@@ -512,6 +558,61 @@ class ConvEngine(object):
         self._prof_add(base, 'k_upsample_add', (n, h, w, c, len(terms)), 2 * (2 * base.numel() + sum(t.numel() for t in terms)), 0, launch)
         return y
 
+    def fuse_sum(self, op, base, plain, srcs, relu=True, tile=(0, 0)):
+        """One output of an HR module's fuse layer in one launch (k_fuse_sum): relu(base + sum plain + sum up(conv1x1(src))).
+        op: PackedUp; plain: tensors of base's shape (channel slices allowed); srcs: the coarser branches' tensors in op's order."""
+        n, c, h, w = base.shape
+        assert c == op.c and len(srcs) == len(op.shifts) and len(plain) <= 2
+        y = self._new(n, c, h, w, base.device)
+        nbytes = 2 * (2 * base.numel() + sum(t.numel() for t in plain) + sum(t.numel() for t in srcs) + sum(c * cs for cs in op.chans)) + 4 * c * len(srcs)
+        flops = sum(2 * t.shape[0] * t.shape[2] * t.shape[3] * t.shape[1] * c for t in srcs)
+        if self.count is not None:
+            self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
+        if base.device.type == 'meta':
+            return y
+        for t, sh, cs in zip(srcs, op.shifts, op.chans):
+            assert tuple(t.shape) == (n, cs, h >> sh, w >> sh) and t.is_contiguous(memory_format=torch.channels_last), (t.shape, base.shape, sh)
+        pp = (C.c_void_p * 2)(*[C.c_void_p(t.data_ptr()) for t in plain] + [None] * (2 - len(plain)))
+        pcs = (C.c_int32 * 2)(*([t.stride(3) for t in plain] + [0] * (2 - len(plain))))
+        sp = (C.c_void_p * len(srcs))(*[C.c_void_p(t.data_ptr()) for t in srcs])
+        launch = lambda: self.lib.pam_fuse_sum_nhwc_bf16(
+            C.c_void_p(torch.cuda.current_stream(base.device).cuda_stream), C.c_void_p(base.data_ptr()), len(plain), pp, pcs, len(srcs), sp,
+            op.c_sh, op.c_ch, op.c_w, op.c_b, C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0, int(tile[0]), int(tile[1]))
+        rc = launch()
+        if rc != 0:
+            raise _lib.PamError('pam_fuse_sum_nhwc_bf16 failed (%d) for %s' % (rc, tuple(base.shape)))
+        self._prof_add(base, 'k_fuse_sum', (n, h, w, c, len(plain), len(srcs)), nbytes, flops, launch)
+        return y
+
+    down48 = True               # 3x3 stride-2 layers with 48 input channels on k_down48 (csrc/pam_down.hip); False: the generic kernels
+    d48_tile = None             # (rows, cols, slab groups) instead of the library's choice (tuning)
+
+    def conv_down48(self, op, x, res=None, relu=False, relu_from=0):
+        """3x3 stride-2 convolution of a 48-channel input (a channel slice of a wider tensor is fine) through k_down48."""
+        n, cin, h, w = x.shape
+        assert cin == 48 and op.cin == 48 and op.stride == 2 and op.kh == 3 and op.pad == 1
+        in_cs = cin if x.device.type == 'meta' else x.stride(3)
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = self._new(n, op.cout, ho, wo, x.device)
+        nbytes = 2 * (x.numel() + y.numel() + op.cout * 9 * 48 + (y.numel() if res is not None else 0)) + 4 * op.cout
+        flops = 2 * y.numel() * 9 * 48
+        if self.count is not None:
+            self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
+        if x.device.type == 'meta':
+            return y
+        assert x.stride(1) == 1 and x.stride(2) == w * in_cs and x.stride(0) == h * w * in_cs, (x.shape, x.stride())
+        img = down48_image(op)
+        t = self.d48_tile or (0, 0, 0)
+        launch = lambda: self.lib.pam_conv3x3s2_c48_nhwc_bf16(
+            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()), in_cs, C.c_void_p(img.data_ptr()),
+            C.c_void_p(op.bias.data_ptr()), C.c_void_p(res.data_ptr()) if res is not None else None, op.cout if res is not None else 0,
+            C.c_void_p(y.data_ptr()), op.cout, n, h, w, op.cout, 1 if relu else 0, int(relu_from), int(t[0]), int(t[1]), int(t[2]))
+        rc = launch()
+        if rc != 0:
+            raise _lib.PamError('pam_conv3x3s2_c48_nhwc_bf16 failed (%d) for %s -> %d' % (rc, tuple(x.shape), op.cout))
+        self._prof_add(x, 'k_down48 3x3 stride 2 C=48 %dx%d' % (h, w), (n, h, w, op.cout, res is not None, in_cs, relu_from), nbytes, flops, launch)
+        return y
+
     def upsample_concat(self, a, b):
         """Darknet upsample(x2) + route: concat(nearest_up2(a), b) along channels."""
         n, ca, h2, w2 = a.shape
@@ -609,7 +710,12 @@ class HipHRNet(ConvEngine):
                 for i, f in ups:
                     parts.append((i, off, f[0].out_channels, j - i)); off += f[0].out_channels
                 merged_up[j] = dict(op=op, parts=parts)
-        return dict(branches=branches, fused=fused, fuse=fuse, merged=merged, merged_up=merged_up)
+        # and the same 1x1 convolutions grouped by OUTPUT for the fused sum (k_fuse_sum: the products never reach HBM)
+        fsum = []
+        for i, row in enumerate(hm.fuse_layers):
+            ups = [(j, row[j][0]) for j in range(len(row)) if j > i and row[j] is not None]
+            fsum.append(dict(op=PackedUp([f for _, f in ups], [j - i for j, _ in ups], self.device), srcs=[j for j, _ in ups]) if ups else None)
+        return dict(branches=branches, fused=fused, fuse=fuse, merged=merged, merged_up=merged_up, fsum=fsum)
 
     # -- network ------------------------------------------------------------------------------------------------------
     # Stream plan (stream 0 = the caller's stream; hipGraph-capturable -- pairwise event dependencies between the branch streams
@@ -655,6 +761,8 @@ class HipHRNet(ConvEngine):
                                 # 96-channel branch on the streamed-weights fused block (k_bblock2_96) -- csrc/pam_block2.hip
     c96_slab = 48               # 96 -> 96 layers that are NOT fused: k_conv3x3s with 48-channel slabs (0 = k_conv3x3)
     stamp = None                # diagnostics (tools/fwd_stamps.py): callable(tag) issued on the current stream at points of the schedule
+    fused_sums = True           # round 5: the fuse layers' 1x1 up-convolutions inside the sum launch (k_fuse_sum); False: one merged 1x1 launch per
+                                # source branch + k_upsample_add
     knock_conv2 = 0             # diagnostics: 1 = the second convolution of every un-fused BasicBlock is not issued
     knock_up = 0                # diagnostics: 1 = the coarsest branch's merged 1x1 up-convolution is not issued (its output stays uninitialised)
     knock_out = 0               # diagnostics: bit b = skip the BasicBlocks of branch b (what a free branch would be worth: tools/ab_flags.py)
@@ -701,7 +809,7 @@ class HipHRNet(ConvEngine):
                 if mg is not None:                                    # first conv of all down chains from this branch in one launch
                     y = self.conv(mg['op'], x, relu=True, relu_from=mg['relu_from'])
                     heads = {i: y[:, off:off + c] for i, off, c, _ in mg['parts']}
-                mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up) else None
+                mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up and not self.fused_sums) else None
                 if mu is not None:                                    # all 1x1 up-convolutions from this branch in one launch
                     if self.knock_up and b == len(mod['branches']) - 1:   # diagnostics: what the last finisher's tail is worth
                         y = self._new(x.shape[0], mu['op'].cout, x.shape[2], x.shape[3], x.device)
@@ -711,7 +819,7 @@ class HipHRNet(ConvEngine):
                         terms[i][b] = (y[:, off:off + c], sh)
                 for i, row in enumerate(fuse):
                     f = row[b] if b < len(row) else None
-                    if f is None or (f[0] == 'up' and mu is not None):
+                    if f is None or (f[0] == 'up' and (mu is not None or self.fused_sums)):
                         continue
                     if f[0] == 'up':
                         terms[i][b] = (self.conv(f[1], x), f[2])
@@ -729,7 +837,11 @@ class HipHRNet(ConvEngine):
         for i in [q for q in self.order if q < len(fuse)]:
             with torch.cuda.stream(self._stream(i)):
                 tl = [terms[i][j] for j in sorted(terms[i])]
-                out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])
+                fs = mod['fsum'][i] if self.fused_sums else None
+                if fs is not None:                                    # plain (down-chain) terms + the coarser branches through their 1x1 products
+                    out[i] = self.fuse_sum(fs['op'], xs[i], [t for t, _ in tl], [xs[j] for j in fs['srcs']], relu=True)
+                else:
+                    out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])
                 self._st('sum%d' % i)
         return out
 

@@ -86,6 +86,7 @@ def test_conv_vs_torch(eng, case, tile):
     res = torch.randn((n, cout, ho, wo), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=torch.channels_last) if use_res else None
     e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
     e.lib = _lib.load(); e.device = dev; e.tile_cfg = tile
+    e.down48 = tile == -1                        # a stated tile keeps the strided 48-channel layers on the generic kernels (k_down48: tests/test_gpu_fuse.py)
     y = e.conv(op, x, res=res, relu=relu)
     wq = conv.weight.detach().to(torch.bfloat16).float().to(dev)
     ref = F.conv2d(x.float(), wq, conv.bias.detach().to(dev), stride, k // 2)
