@@ -325,9 +325,10 @@ int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const void* x0, 
  * bias_s)): base / out / plain_t (N, H, W, C) NHWC bf16, C in {48, 96, 192} (plain_t may be channel slices: plain_cstrides, NULL = C);
  * src_s (N, H >> shift_s, W >> shift_s, up_channels[s]) with ascending shifts, up_channels % 32 == 0, H and W multiples of 2^shift;
  * up_wimg[s]: the 1x1 weights (C x up_channels[s]) as MFMA A fragments, bf16 [C / 16][up_channels / 32][64 lanes][8]: lane l of fragment
- * (j, ks) holds W[16 j + (l & 15)][32 ks + 8 (l >> 4) .. + 7]; up_bias[s]: float32 [C] or NULL.  n_plain <= 2, 1 <= n_up <= 3.  The 1x1
- * products are computed per tile of tile_a x tile_b pixels of the coarsest source (<= 0: the library's choice) and never reach HBM;
- * sum order = base, plain terms, up terms (the order of pam_upsample_add_nhwc_bf16 with the terms in branch order).  Results are
+ * (j, ks) holds W[16 j + (l & 15)][32 ks + 8 (l >> 4) .. + 7]; up_bias[s]: float32 [C] or NULL.  n_plain <= 2, 1 <= n_up <= 3.  Persistent
+ * workgroups (at most one per CU, at most max_workgroups when that is > 0: several outputs of a module then share the chip) keep all the
+ * 1x1 weights in LDS and walk tiles of tile_a x tile_b pixels of the coarsest source (<= 0: the library's choice, 1 x 3); the products
+ * never reach HBM; sum order = base, plain terms, up terms (the order of pam_upsample_add_nhwc_bf16 with the terms in branch order).  Results are
  * bit-identical to pam_conv2d_nhwc_bf16 (1x1) per source followed by pam_upsample_add_nhwc_bf16. */
 int pam_conv3x3s2_c48_tile(int N, int H, int W, int Cout, int32_t* out3);
 int pam_conv3x3s2_c48_nhwc_bf16(void* stream, const void* in, int in_cstride, const void* wpack, const float* bias, const void* res,
@@ -335,7 +336,8 @@ int pam_conv3x3s2_c48_nhwc_bf16(void* stream, const void* in, int in_cstride, co
                                 int tile_rows, int tile_cols, int slab_groups);
 int pam_fuse_sum_nhwc_bf16(void* stream, const void* base, int n_plain, const void* const* plain, const int32_t* plain_cstrides, int n_up,
                            const void* const* up_src, const int32_t* up_shifts, const int32_t* up_channels, const void* const* up_wimg,
-                           const float* const* up_bias, void* out, int N, int H, int W, int C, int relu, int tile_a, int tile_b);
+                           const float* const* up_bias, void* out, int N, int H, int W, int C, int relu, int tile_a, int tile_b,
+                           int max_workgroups);
 
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before

@@ -558,7 +558,7 @@ class ConvEngine(object):
         self._prof_add(base, 'k_upsample_add', (n, h, w, c, len(terms)), 2 * (2 * base.numel() + sum(t.numel() for t in terms)), 0, launch)
         return y
 
-    def fuse_sum(self, op, base, plain, srcs, relu=True, tile=(0, 0)):
+    def fuse_sum(self, op, base, plain, srcs, relu=True, tile=(0, 0), max_wg=0):
         """One output of an HR module's fuse layer in one launch (k_fuse_sum): relu(base + sum plain + sum up(conv1x1(src))).
         op: PackedUp; plain: tensors of base's shape (channel slices allowed); srcs: the coarser branches' tensors in op's order."""
         n, c, h, w = base.shape
@@ -577,7 +577,7 @@ class ConvEngine(object):
         sp = (C.c_void_p * len(srcs))(*[C.c_void_p(t.data_ptr()) for t in srcs])
         launch = lambda: self.lib.pam_fuse_sum_nhwc_bf16(
             C.c_void_p(torch.cuda.current_stream(base.device).cuda_stream), C.c_void_p(base.data_ptr()), len(plain), pp, pcs, len(srcs), sp,
-            op.c_sh, op.c_ch, op.c_w, op.c_b, C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0, int(tile[0]), int(tile[1]))
+            op.c_sh, op.c_ch, op.c_w, op.c_b, C.c_void_p(y.data_ptr()), n, h, w, c, 1 if relu else 0, int(tile[0]), int(tile[1]), int(max_wg))
         rc = launch()
         if rc != 0:
             raise _lib.PamError('pam_fuse_sum_nhwc_bf16 failed (%d) for %s' % (rc, tuple(base.shape)))
@@ -761,8 +761,13 @@ class HipHRNet(ConvEngine):
                                 # 96-channel branch on the streamed-weights fused block (k_bblock2_96) -- csrc/pam_block2.hip
     c96_slab = 48               # 96 -> 96 layers that are NOT fused: k_conv3x3s with 48-channel slabs (0 = k_conv3x3)
     stamp = None                # diagnostics (tools/fwd_stamps.py): callable(tag) issued on the current stream at points of the schedule
-    fused_sums = True           # round 5: the fuse layers' 1x1 up-convolutions inside the sum launch (k_fuse_sum); False: one merged 1x1 launch per
-                                # source branch + k_upsample_add
+    fs_cap = (0, 0, 0, 0)       # workgroups of output i's fused sum at most (0 = one per CU): the sums of a module's outputs run side by side
+    fused_sums = False          # round 5: True = the fuse layers' 1x1 up-convolutions inside the sum launch (k_fuse_sum: 203 launches instead of 221,
+                                # bit-identical); False = one merged 1x1 launch per source branch + k_upsample_add.  Measured at 20 crops,
+                                # interleaved A/B: -1.5 ... +0.3 % per forward -- the 1x1 launches ran beside the other branches' blocks and
+                                # were hidden, while the sums sit behind the module's join on the critical path and a persistent
+                                # one-workgroup-per-CU kernel (the weights take 64-147 KB of LDS) streams slower than k_upsample_add's
+                                # many small workgroups (20.9 vs 7.9 us for output 0 of a stage-4 module).  Off by default.
     knock_conv2 = 0             # diagnostics: 1 = the second convolution of every un-fused BasicBlock is not issued
     knock_up = 0                # diagnostics: 1 = the coarsest branch's merged 1x1 up-convolution is not issued (its output stays uninitialised)
     knock_out = 0               # diagnostics: bit b = skip the BasicBlocks of branch b (what a free branch would be worth: tools/ab_flags.py)
@@ -839,7 +844,7 @@ class HipHRNet(ConvEngine):
                 tl = [terms[i][j] for j in sorted(terms[i])]
                 fs = mod['fsum'][i] if self.fused_sums else None
                 if fs is not None:                                    # plain (down-chain) terms + the coarser branches through their 1x1 products
-                    out[i] = self.fuse_sum(fs['op'], xs[i], [t for t, _ in tl], [xs[j] for j in fs['srcs']], relu=True)
+                    out[i] = self.fuse_sum(fs['op'], xs[i], [t for t, _ in tl], [xs[j] for j in fs['srcs']], relu=True, max_wg=self.fs_cap[i])
                 else:
                     out[i] = self.upsample_add(xs[i], [t for t, _ in tl], [sh for _, sh in tl], relu=True) if tl else torch.relu(xs[i])
                 self._st('sum%d' % i)

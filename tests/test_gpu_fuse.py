@@ -169,24 +169,24 @@ def test_fuse_sum_argument_checks(eng):
     assert y.shape == base.shape
 
 
-def test_forward_with_fused_sums_equals_the_unfused_forward():
-    """The whole conv stack with k_down48 + k_fuse_sum (the default) against the same network on the generic strided kernel + separate 1x1
-    launches + k_upsample_add: bit-identical features, 203 instead of 221 launches."""
+def test_forward_with_the_round5_kernels_equals_the_forward_without_them():
+    """The whole conv stack with k_down48 (default) and, optionally, k_fuse_sum against the same network on the generic strided kernel +
+    separate 1x1 launches + k_upsample_add: bit-identical features; 203 launches with the fused sums, 221 without."""
     from pam import hrnet
     net = hrnet.HRNetPose(48, 17, None, use_graph=False)
     x = net.input_buffer(3)
     x.copy_(torch.randn(x.shape, device=net.device).to(x.dtype)); x[:, 3:] = 0
     hip = net.hip
-    hip.count = dict(bytes=0, flops=0, launches=0)
-    f1 = hip.features(x).clone()
-    l1 = hip.count['launches']
-    hip.fused_sums, hip.down48 = False, False
-    hip.count = dict(bytes=0, flops=0, launches=0)
+    feats, launches = {}, {}
     try:
-        f0 = hip.features(x).clone()
-        l0 = hip.count['launches']
+        for name, fs, d48 in (('old', False, False), ('d48', False, True), ('both', True, True)):
+            hip.fused_sums, hip.down48 = fs, d48
+            hip.count = dict(bytes=0, flops=0, launches=0)
+            feats[name] = hip.features(x).clone()
+            launches[name] = hip.count['launches']
     finally:
-        hip.fused_sums, hip.down48, hip.count = True, True, None
+        del hip.fused_sums, hip.down48
+        hip.count = None
     torch.cuda.synchronize()
-    assert (l1, l0) == (203, 221), (l1, l0)
-    assert torch.equal(f0, f1), (f0.float() - f1.float()).abs().max().item()
+    assert launches == dict(old=221, d48=221, both=203), launches
+    assert torch.equal(feats['old'], feats['d48']) and torch.equal(feats['old'], feats['both'])
