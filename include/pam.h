@@ -331,6 +331,15 @@ int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const void* x0, 
  * never reach HBM; sum order = base, plain terms, up terms (the order of pam_upsample_add_nhwc_bf16 with the terms in branch order).  Results are
  * bit-identical to pam_conv2d_nhwc_bf16 (1x1) per source followed by pam_upsample_add_nhwc_bf16. */
 int pam_conv3x3s2_c48_tile(int N, int H, int W, int Cout, int32_t* out3);
+/* the same convolution for Cin = 96 / 192 (k_down_s: the streamed 3x3 kernel with a stride-2, parity-planar patch; no residual).
+ * pam_conv3x3s2_slab: the slab width BN (64 or 48 output channels) the library takes for this shape, 0 = not taken (generic kernel);
+ * w_img: the streamed 3x3 image of pam_conv2d_nhwc_bf16 for that BN ([Cout / BN][Cin / 32][9 taps][BN rows][4 pieces of 8 bf16]: row
+ * j*16 + q of a slab = its channel 4*(BN/16)*(q >> 2) + 4*j + (q & 3), physical piece p of row r = the chunk's input channels
+ * 8*(p ^ ((r >> 1) & 2)) .. + 7).  relu_from % 16 == 0.  Equal to pam_conv2d_nhwc_bf16 up to the summation order (K walked chunk by
+ * chunk of 32 input channels instead of tap by tap): within one bf16 rounding of the fp32 result. */
+int pam_conv3x3s2_slab(int H, int W, int Cin, int Cout);
+int pam_conv3x3s2_nhwc_bf16(void* stream, const void* in, int in_cstride, const void* w_img, const float* bias, void* out, int N, int H,
+                            int W, int Cin, int Cout, int relu, int relu_from);
 int pam_conv3x3s2_c48_nhwc_bf16(void* stream, const void* in, int in_cstride, const void* wpack, const float* bias, const void* res,
                                 int res_cstride, void* out, int out_cstride, int N, int H, int W, int Cout, int relu, int relu_from,
                                 int tile_rows, int tile_cols, int slab_groups);

@@ -81,6 +81,8 @@ _SIGS = {
     'pam_bottleneck_tail_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I]),
     'pam_conv3x3s2_c48_tile': (_I, [_I, _I, _I, _I, _P]),
     'pam_conv3x3s2_c48_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P, _I, _P, _I] + [_I] * 9),
+    'pam_conv3x3s2_slab': (_I, [_I, _I, _I, _I]),
+    'pam_conv3x3s2_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P] + [_I] * 7),
     'pam_fuse_sum_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 8),
     'pam_comm_unique_id': (_I, [_P]),
     'pam_comm_init': (_I, [C.POINTER(_P), _I, _I, _P, _I]),

@@ -283,6 +283,200 @@ bool d48_pick(int N, int Ho, int Wo, int nslab, int& TR, int& TC, int& G) {
     return true;
 }
 
+
+// ====================================================================================================================================
+// k_down_s (Cin = 96 / 192: the other 12 strided layers): the streamed 3x3 kernel of csrc/pam_conv.hip (k_conv3x3s: loader waves 4-7 move
+// 32-channel chunks -- patch rows + the chunk's [9 taps][BN rows] weight image -- by LDS-DMA into a ring of chunk buffers, multiplier
+// waves 0-3 read fragments and multiply) with a STRIDE-2 patch: tile = TH output rows x the full output width, patch = (2 TH + 1) rows of
+// PWp = 2 Wo + 2 slots of 64 B, the columns of a row stored by parity (even patch columns in slots 0 .. Wo, odd ones in Wo + 1 .. 2 Wo), so
+// the taps kx = 0, 1, 2 of output column c are slots c, Wo + 1 + c, c + 1 and a 16-position M tile reads (runs of) consecutive slots:
+// the conflict-free ds_read_b128 pattern of the stride-1 kernel (piece g of slot r at position g ^ ((r >> 1) & 2)).  The loaders'
+// per-lane source addresses do the de-interleaving (and take the channel stride of a sliced input); the weight images are the
+// stride-1 kernel's ([slab][chunk][tap][row][4 pieces], rows permuted so that a lane ends with 4 NTW contiguous channels).
+// The generic gather kernel spent 13 VALU + SALU instructions per MFMA on im2col addresses; here a multiplier lane holds MT x 9 offsets.
+// ====================================================================================================================================
+struct DSArgs {
+    const uint16_t* in; const uint16_t* wimg; const float* bias; uint16_t* out;
+    int N, H, W, Ho, Wo, in_cs, Cout, TH, tiles_y, relu, relu_from;
+    float inv_pwp, inv_wo;
+};
+
+template <int NTW>
+__device__ __forceinline__ void ds_row_store(uint16_t* p, int g, const uint32_t* d) {
+    if constexpr (NTW == 4) {
+        *(u32x4*)p = (u32x4){d[0], d[1], d[2], d[3]}; *(u32x4*)(p + 8) = (u32x4){d[4], d[5], d[6], d[7]};
+    } else {
+        static_assert(NTW == 3, "slab width");            // 24 bytes: 16 + 8 for even g, 8 + 16 for odd g (the 16-byte half stays aligned)
+        const bool odd = g & 1;
+        *(u32x4*)(p + (odd ? 4 : 0)) = odd ? (u32x4){d[2], d[3], d[4], d[5]} : (u32x4){d[0], d[1], d[2], d[3]};
+        *(u32x2*)(p + (odd ? 0 : 8)) = odd ? (u32x2){d[0], d[1]} : (u32x2){d[4], d[5]};
+    }
+}
+
+template <int CIN, int NTW, int MT, int PMAX, int NBUF>
+__global__ __launch_bounds__(512, 1) void k_down_s(DSArgs a) {
+    constexpr int BN = 16 * NTW, NCHUNK = CIN / 32;
+    constexpr int PIMG = PMAX * 64, WIMGS = 9 * BN * 64, BUF = PIMG + WIMGS;
+    constexpr int PPW = PMAX / 64, WPIECES = WIMGS / 1024, WPWS = (WPIECES + 3) / 4, NPER = PPW + WPWS;   // DMA pieces per loader wave per chunk
+    static_assert(PMAX % 64 == 0 && WIMGS % 1024 == 0 && NPER * (NBUF - 1) <= 60 && NBUF >= 2 && NBUF <= 3, "ring shape");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = a.tiles_y * a.N;
+    const int bx = [&] {                                // XCD-aware tile order: every XCD gets a contiguous run of tiles
+        const int v = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, xcd = v & 7, loc = v >> 3;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }();
+    const int n = bx / a.tiles_y, ty0 = (bx - n * a.tiles_y) * a.TH;                     // first OUTPUT row of the tile
+    const int NEp = a.Wo + 1, PWp = 2 * a.Wo + 2, npatch = (2 * a.TH + 1) * PWp;
+    const int npos = min(a.TH, a.Ho - ty0) * a.Wo;                                       // output positions of this tile
+    const int n0 = blockIdx.y * BN;
+
+    if (wave >= 4) {
+        // ---- loader waves ---------------------------------------------------------------------------------------------------
+        const int lw = wave - 4;
+        const char* psrc[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int s = (lw + 4 * i) * 16 + (lane >> 2);                               // slot this lane fills in piece lw + 4 i
+            const int gsrc = (lane & 3) ^ ((s >> 1) & 2);
+            const int py = fdiv_small(s, a.inv_pwp), q = s - py * PWp;
+            const int c = q < NEp ? 2 * q : 2 * (q - NEp) + 1;                            // patch column of slot q (q = 2 Wo + 1: the pad slot)
+            const int iy = 2 * ty0 - 1 + py, ix = c - 1;
+            const bool ok = s < npatch && q <= 2 * a.Wo && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            psrc[i] = ok ? (const char*)a.in + (((size_t)n * a.H + iy) * a.W + ix) * (size_t)(a.in_cs * 2) + gsrc * 16 : (const char*)g_d48_zero;
+        }
+        const char* wsrc = (const char*)a.wimg + (size_t)blockIdx.y * NCHUNK * WIMGS + lane * 16;
+        auto issue = [&](int c) {
+            char* dst = smem + (size_t)((unsigned)c % (unsigned)NBUF) * BUF;
+#pragma unroll
+            for (int i = 0; i < (PPW > WPWS ? PPW : WPWS); ++i) {
+                if (i < WPWS) {
+                    const int j = min(lw + 4 * i, WPIECES - 1);                          // a wave short of a piece re-sends the last one
+                    __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + (size_t)c * WIMGS + j * 1024), (lds_void*)(dst + PIMG + j * 1024), 16, 0, 0);
+                }
+                if (i < PPW) {
+                    const bool z = psrc[i] == (const char*)g_d48_zero;                   // padding / outside the image: the page of zeros, whatever the chunk
+                    __builtin_amdgcn_global_load_lds((glb_void*)(psrc[i] + (z ? 0 : c * 64)), (lds_void*)(dst + (lw + 4 * i) * 1024), 16, 0, 0);
+                }
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < NBUF - 1; ++c)
+            if (c < NCHUNK) issue(c);
+        for (int k = 0; k < NCHUNK; ++k) {
+            const int fly = min(NCHUNK - 1 - k, NBUF - 2);                               // younger chunks that may stay in flight
+            if (fly <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
+            asm volatile("s_barrier" ::: "memory");
+            if (k + NBUF - 1 < NCHUNK) issue(k + NBUF - 1);
+        }
+        return;
+    }
+
+    // ---- multiplier waves ---------------------------------------------------------------------------------------------------
+    f32x4 acc[MT][NTW];
+    {
+        f32x4 bias4[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[i][j] = bias4[j];
+    }
+    // LDS byte offsets (inside a chunk buffer) of this lane's patch fragment for M tile i and tap t, swizzle included
+    unsigned aoff[MT][9];
+    int opix[MT];                                                                        // output pixel of the lane's position (-1: none)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (wave * MT + i) * 16 + (lane & 15);
+        const int mm = m < npos ? m : 0;
+        const int oy = fdiv_small(mm, a.inv_wo), ox = mm - oy * a.Wo;
+        opix[i] = m < npos ? ((n * a.Ho + ty0 + oy) * a.Wo + ox) : -1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            const int s = (2 * oy + ky) * PWp + ox + (kx == 1 ? NEp : (kx == 2 ? 1 : 0));
+            aoff[i][t] = (unsigned)(s * 64 + ((g ^ ((s >> 1) & 2)) << 4));
+        }
+    }
+    const unsigned woff = (unsigned)(PIMG + (lane & 15) * 64 + ((g ^ ((lane >> 1) & 2)) << 4));   // row j*16 + (lane & 15): bit 2 of the row = bit 2 of the lane
+
+    bf16x8 af[2][MT], bfr[2][NTW];
+    auto ldfrag = [&](int k, int t, bf16x8* af_, bf16x8* bf_) {
+        const char* buf = smem + (size_t)((unsigned)k % (unsigned)NBUF) * BUF;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bf_[j] = *(const bf16x8*)(buf + woff + (t * BN + j * 16) * 64);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af_[i] = *(const bf16x8*)(buf + aoff[i][t]);
+    };
+    auto chunk = [&](int k, auto PARC) {
+        constexpr int PAR = decltype(PARC)::value;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int cur = (t + PAR) & 1, nxt = cur ^ 1;
+            if (t + 1 < 9) ldfrag(k, t + 1, af[nxt], bfr[nxt]);
+            else if (k + 1 < NCHUNK) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);                                       // lgkmcnt(0): this wave is done reading chunk k
+                asm volatile("s_barrier" ::: "memory");                                   // chunk k + 1 has landed; chunk k's buffer is free
+                ldfrag(k + 1, 0, af[nxt], bfr[nxt]);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[cur][j]),
+                                                                       __builtin_bit_cast(bf16x8_t, af[cur][i]), acc[i][j], 0, 0, 0);
+            spread<MT * NTW, MT + NTW>(std::make_integer_sequence<int, MT + NTW>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    asm volatile("s_barrier" ::: "memory");                                              // chunk 0 has landed (and is visible)
+    ldfrag(0, 0, af[0], bfr[0]);
+    for (int k = 0; k < NCHUNK; k += 2) {
+        chunk(k, std::integral_constant<int, 0>{});
+        if (k + 1 < NCHUNK) chunk(k + 1, std::integral_constant<int, 1>{});
+    }
+    // ---- epilogue straight from the accumulators: 4 NTW contiguous channels of one pixel per lane
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (opix[i] < 0) continue;
+        uint32_t ov[2 * NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            ov[2 * j] = pack_bf16x2(acc[i][j][0], acc[i][j][1]); ov[2 * j + 1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+            if (a.relu && n0 + g * 4 * NTW + j * 4 >= a.relu_from) { ov[2 * j] = relu_bf16x2(ov[2 * j]); ov[2 * j + 1] = relu_bf16x2(ov[2 * j + 1]); }
+        }
+        ds_row_store<NTW>(a.out + (size_t)opix[i] * a.Cout + n0 + g * 4 * NTW, g, ov);
+    }
+}
+
+// rows per tile and the instantiation: M tiles per multiplier wave x patch slots.  false = this layer stays on the generic kernels
+bool ds_pick(int Ho, int Wo, int Cin, int Cout, int& TH, int& bn) {
+    if (Cin != 96 && Cin != 192) return false;
+    bn = Cout % 64 == 0 ? 64 : (Cout % 48 == 0 ? 48 : 0);
+    if (!bn) return false;
+    const int PWp = 2 * Wo + 2;
+    TH = 0;
+    long best = 0;
+    for (int t = Ho; t >= 1; --t) {                     // the tile height that costs the fewest workgroups x M tiles; at most 8 M tiles, 512 slots
+        if (t * Wo > 128 || (2 * t + 1) * PWp > 512) continue;
+        const long cost = (Ho + t - 1) / t;
+        if (TH == 0 || cost < best) { TH = t; best = cost; }
+    }
+    return TH >= 1;
+}
+template <int CIN, int NTW>
+int launch_ds(hipStream_t s, const DSArgs& a) {
+    constexpr int MT = 2, PMAX = 512, NBUF = 2;
+    constexpr size_t lds = (size_t)NBUF * (PMAX * 64 + 9 * 16 * NTW * 64);
+    static_assert(lds <= 160 * 1024, "LDS");
+    if (!pam_max_dynamic_lds((const void*)k_down_s<CIN, NTW, MT, PMAX, NBUF>, (int)lds)) return PAM_E_HIP;
+    pam_launch(k_down_s<CIN, NTW, MT, PMAX, NBUF>, dim3(a.tiles_y * a.N, a.Cout / (16 * NTW)), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
 }  // namespace
 
 // wpack: Cout / 48 slab images of 43 008 bytes, slab s = output channels 48 s .. 48 s + 47: [14 k-steps][48 rows][64 bytes] exactly as one
@@ -334,4 +528,33 @@ extern "C" int pam_conv3x3s2_c48_nhwc_bf16(void* stream, const void* in, int in_
     if (!pam_max_dynamic_lds((const void*)k_down48, 160 * 1024)) return PAM_E_HIP;
     pam_launch(k_down48, dim3(a.nitems, G), dim3(512), lds, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+// Cin = 96 / 192 on the streamed kernel with a stride-2 patch (k_down_s).  w_img: the streamed 3x3 image of pam_conv2d_nhwc_bf16
+// ([Cout / BN][Cin / 32][9 taps][BN rows][4 pieces of 8 bf16], see there) for BN = pam_conv3x3s2_slab(); 0 = this shape is not taken.
+extern "C" int pam_conv3x3s2_slab(int H, int W, int Cin, int Cout) {
+    int th = 0, bn = 0;
+    if (H < 2 || W < 2) return 0;
+    return ds_pick((H - 1) / 2 + 1, (W - 1) / 2 + 1, Cin, Cout, th, bn) ? bn : 0;
+}
+extern "C" int pam_conv3x3s2_nhwc_bf16(void* stream, const void* in, int in_cstride, const void* w_img, const float* bias, void* out,
+                                       int N, int H, int W, int Cin, int Cout, int relu, int relu_from) {
+    if (!in || !w_img || !out || N < 1 || H < 2 || W < 2 || in_cstride < Cin || in_cstride % 8 != 0 || relu_from < 0 || relu_from % 16 != 0) return PAM_E_ARG;
+    DSArgs a;
+    a.in = (const uint16_t*)in; a.wimg = (const uint16_t*)w_img; a.bias = bias; a.out = (uint16_t*)out;
+    a.N = N; a.H = H; a.W = W; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1; a.in_cs = in_cstride; a.Cout = Cout;
+    a.relu = relu ? 1 : 0; a.relu_from = relu_from;
+    int bn = 0;
+    if (!ds_pick(a.Ho, a.Wo, Cin, Cout, a.TH, bn)) return PAM_E_ARG;
+    if ((size_t)N * a.Ho * a.Wo >= (1ull << 31) || (size_t)N * H * W * in_cstride * 2 >= (1ull << 40)) return PAM_E_ARG;
+    a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
+    a.inv_pwp = 1.0f / (float)(2 * a.Wo + 2); a.inv_wo = 1.0f / (float)a.Wo;
+    hipStream_t s = (hipStream_t)stream;
+    switch (Cin * 10 + bn / 16) {
+        case 964: return launch_ds<96, 4>(s, a);
+        case 963: return launch_ds<96, 3>(s, a);
+        case 1924: return launch_ds<192, 4>(s, a);
+        case 1923: return launch_ds<192, 3>(s, a);
+    }
+    return PAM_E_ARG;
 }

@@ -133,6 +133,21 @@ def down48_image(op):
     return img
 
 
+def streamed_image(w_ohwi, bn, device):
+    """The streamed 3x3 kernels' weight image (layout: include/pam.h): [cout / bn][cin / 32][9 taps][bn rows][4 pieces][8] -- row j*16 + q
+    of a slab = its channel 4*ntw*(q >> 2) + 4*j + (q & 3) (a lane's accumulators are then 4*ntw contiguous output channels), physical
+    16-byte piece p of row r = the chunk's input channels 8*(p ^ ((r >> 1) & 2)) .. + 7 (LDS bank swizzle)."""
+    cout, _, _, cin = w_ohwi.shape
+    ntw = bn // 16
+    perm = [4 * ntw * (q >> 2) + 4 * j + (q & 3) for j in range(ntw) for q in range(16)]
+    w5 = w_ohwi.reshape(cout // bn, bn, 9, cin // 32, 32)[:, perm]                              # [slab][row][tap][chunk][c]
+    t = w5.permute(0, 3, 2, 1, 4).reshape(cout // bn, cin // 32, 9, bn, 4, 8)                   # [slab][chunk][tap][row][piece][8]
+    rows = torch.arange(bn)
+    src = torch.arange(4)[None, :] ^ ((rows >> 1) & 2)[:, None]
+    t = torch.gather(t, 4, src[None, None, None, :, :, None].expand(t.shape))
+    return t.to(torch.bfloat16).to(device).contiguous()
+
+
 class PackedUp(object):
     """The 1x1 convolutions into ONE output of an HR module's fuse layer, packed for ``pam_fuse_sum_nhwc_bf16`` (csrc/pam_fuse.hip):
     per coarser source branch the weights as MFMA A fragments [C / 16][Cs / 32][64 lanes][8] (lane l of fragment (j, ks) holds
@@ -357,6 +372,10 @@ class ConvEngine(object):
         if (self.down48 and op.stride == 2 and op.kh == 3 and op.kw == 3 and op.pad == 1 and op.cin == 48 and op.cout % 48 == 0 and
                 self.ACT[relu] <= 1 and not res_after_act and relu_from % 8 == 0):
             return self.conv_down48(op, x, res=res, relu=bool(self.ACT[relu]), relu_from=relu_from)
+        if (self.down_s and op.stride == 2 and op.kh == 3 and op.kw == 3 and op.pad == 1 and op.cin in (96, 192) and res is None and
+                self.ACT[relu] <= 1 and relu_from % 16 == 0 and self.tile_cfg == -1 and
+                (x.device.type == 'meta' or self.lib.pam_conv3x3s2_slab(h, w, cin, op.cout) > 0)):
+            return self.conv_down_s(op, x, relu=bool(self.ACT[relu]), relu_from=relu_from)
         in_cs = cin if x.device.type == 'meta' else x.stride(3)          # channels between neighbouring pixels
         assert cin == op.cin and (x.device.type == 'meta' or (x.stride(1) == 1 and x.stride(2) == w * in_cs and x.stride(0) == h * w * in_cs)), (x.shape, op.cin)
         ho = (h + 2 * op.pad - op.kh) // op.stride + 1
@@ -582,6 +601,35 @@ class ConvEngine(object):
         if rc != 0:
             raise _lib.PamError('pam_fuse_sum_nhwc_bf16 failed (%d) for %s' % (rc, tuple(base.shape)))
         self._prof_add(base, 'k_fuse_sum', (n, h, w, c, len(plain), len(srcs)), nbytes, flops, launch)
+        return y
+
+    down_s = True               # 3x3 stride-2 layers with 96 / 192 input channels on k_down_s (csrc/pam_down.hip); False: the generic kernels
+
+    def conv_down_s(self, op, x, relu=False, relu_from=0):
+        """3x3 stride-2 convolution of a 96- / 192-channel input (channel slices allowed) through the streamed stride-2 kernel."""
+        n, cin, h, w = x.shape
+        in_cs = cin if x.device.type == 'meta' else x.stride(3)
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = self._new(n, op.cout, ho, wo, x.device)
+        nbytes = 2 * (x.numel() + y.numel() + op.cout * 9 * cin) + 4 * op.cout
+        flops = 2 * y.numel() * 9 * cin
+        if self.count is not None:
+            self.count['bytes'] += nbytes; self.count['flops'] += flops; self.count['launches'] += 1
+        if x.device.type == 'meta':
+            return y
+        assert x.stride(1) == 1 and x.stride(2) == w * in_cs and x.stride(0) == h * w * in_cs, (x.shape, x.stride())
+        bn = self.lib.pam_conv3x3s2_slab(h, w, cin, op.cout)
+        img = op._images.get(('s2', bn))
+        if img is None:
+            w_ohwi = op.w[:, :9 * cin].float().cpu().reshape(op.cout, 3, 3, cin)               # op.w: [cout][k = (ky, kx, cin)]
+            img = op._images[('s2', bn)] = streamed_image(w_ohwi, bn, op._device)
+        launch = lambda: self.lib.pam_conv3x3s2_nhwc_bf16(
+            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()), in_cs, C.c_void_p(img.data_ptr()),
+            C.c_void_p(op.bias.data_ptr()), C.c_void_p(y.data_ptr()), n, h, w, cin, op.cout, 1 if relu else 0, int(relu_from))
+        rc = launch()
+        if rc != 0:
+            raise _lib.PamError('pam_conv3x3s2_nhwc_bf16 failed (%d) for %s -> %d' % (rc, tuple(x.shape), op.cout))
+        self._prof_add(x, 'k_down_s 3x3 stride 2 C=%d %dx%d' % (cin, h, w), (n, h, w, op.cout, in_cs, relu_from), nbytes, flops, launch)
         return y
 
     down48 = True               # 3x3 stride-2 layers with 48 input channels on k_down48 (csrc/pam_down.hip); False: the generic kernels

@@ -109,6 +109,56 @@ def test_down48_tile_choice_and_limits(eng):
     torch.cuda.synchronize()
 
 
+DS_CASES = [
+    # n, h, w, cin, cout, wide, relu, relu_from
+    (20, 48, 36, 96, 192, 96, False, 0),           # stage 3 / transition 2 at 20 crops: 6-row tiles, 64-channel slabs
+    (20, 48, 36, 96, 288, 96, True, 192),          # the merged head of branch 1 in a stage-4 module: 48-channel slabs, ReLU from channel 192 on
+    (20, 24, 18, 96, 384, 288, False, 0),          # its second level: the input is a channel slice, whole-image tiles
+    (20, 24, 18, 192, 384, 192, False, 0),         # branch 2 -> 3 / transition 3: six chunks
+    (3, 48, 36, 192, 384, 192, True, 0),
+    (2, 31, 23, 96, 192, 96, True, 0),             # odd sizes: padding on all sides, ragged last tile
+    (2, 32, 24, 96, 192, 96, False, 0),            # 256 x 192 crops
+    (3, 7, 5, 192, 192, 192, True, 64),            # tiny image
+    (40, 48, 36, 96, 288, 96, True, 192),
+]
+
+
+@pytest.mark.parametrize('case', DS_CASES)
+def test_down_s_vs_torch(eng, case):
+    """The streamed stride-2 kernel (k_down_s) against fp32 PyTorch; against the generic kernel it differs by the summation order only
+    (K chunk by chunk of 32 input channels instead of tap by tap)."""
+    from pam import hrnet_hip
+    n, h, w, cin, cout, wide, relu, relu_from = case
+    dev = eng.device
+    conv = _conv(cin, cout, 3, 2, 200 + h + cout)
+    op = hrnet_hip.PackedConv(conv, dev)
+    xw = _cl((n, wide, h, w), 17 + n + w, dev)
+    off = (wide - cin) // 2 // 8 * 8
+    x = xw[:, off:off + cin]
+    eng._keep = []
+    assert eng.lib.pam_conv3x3s2_slab(h, w, cin, cout) in (48, 64)
+    y = eng.conv_down_s(op, x, relu=relu, relu_from=relu_from)
+    ref = F.conv2d(x.float(), conv.weight.detach().to(torch.bfloat16).float().to(dev), conv.bias.detach().to(dev), 2, 1)
+    if relu:
+        ref = torch.cat([ref[:, :relu_from], torch.relu(ref[:, relu_from:])], 1)
+    eng.down_s = False
+    try:
+        y0 = eng.conv(op, x, relu=relu, relu_from=relu_from)
+    finally:
+        eng.down_s = True
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape
+    err = (y.float() - ref).abs()
+    tol = 2.0 ** -7 * ref.abs() + 2e-2
+    assert bool((err <= tol).all()), (case, err.max().item())
+    assert float((y.float() - y0.float()).abs().max()) <= float(2.0 ** -6 * ref.abs().max() + 2e-2)
+
+
+def test_down_s_declines_what_it_does_not_take(eng):
+    assert eng.lib.pam_conv3x3s2_slab(48, 36, 48, 96) == 0 and eng.lib.pam_conv3x3s2_slab(48, 36, 96, 100) == 0
+    assert eng.lib.pam_conv3x3s2_slab(400, 300, 96, 192) == 0                         # rows too wide for the 512-slot patch
+
+
 FS_CASES = [
     # n, h, w, c, shifts of the coarser sources, number of plain terms, tile (a, b) or None
     (2, 96, 72, 48, (1, 2, 3), 0, None),           # output 0 of a stage-4 module
@@ -179,14 +229,17 @@ def test_forward_with_the_round5_kernels_equals_the_forward_without_them():
     hip = net.hip
     feats, launches = {}, {}
     try:
-        for name, fs, d48 in (('old', False, False), ('d48', False, True), ('both', True, True)):
-            hip.fused_sums, hip.down48 = fs, d48
+        for name, fs, d48, ds in (('old', False, False, False), ('d48', False, True, False), ('both', True, True, False), ('default', False, True, True)):
+            hip.fused_sums, hip.down48, hip.down_s = fs, d48, ds
             hip.count = dict(bytes=0, flops=0, launches=0)
             feats[name] = hip.features(x).clone()
             launches[name] = hip.count['launches']
     finally:
-        del hip.fused_sums, hip.down48
+        del hip.fused_sums, hip.down48, hip.down_s
         hip.count = None
     torch.cuda.synchronize()
-    assert launches == dict(old=221, d48=221, both=203), launches
+    assert launches == dict(old=221, d48=221, both=203, default=221), launches
     assert torch.equal(feats['old'], feats['d48']) and torch.equal(feats['old'], feats['both'])
+    # k_down_s walks K in another order: the features move in the last bf16 bits only
+    rel = float((feats['default'].float() - feats['old'].float()).norm() / feats['old'].float().norm())
+    assert 0 < rel < 5e-3, rel                     # the bf16 stack as a whole is 6e-3 from fp32 (test_gpu_image.py::test_bf16_stack_vs_fp32)

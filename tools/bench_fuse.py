@@ -45,8 +45,13 @@ if a.only in ('', 'down'):
                                            (48, 36, 96, 192, 96, 0, 5), (48, 36, 96, 288, 96, 192, 2), (24, 18, 96, 384, 288, 0, 2), (24, 18, 192, 384, 192, 0, 3)):
         op = hrnet_hip.PackedConv(nn.Conv2d(cin, cout, 3, 2, 1), dev)
         x = cl(wide, h, w)[:, :cin]
-        e.down48 = False
+        e.down48 = e.down_s = False
         t0 = timeit(lambda: e.conv(op, x, relu=True, relu_from=rf))
+        if cin != 48 and e.lib.pam_conv3x3s2_slab(h, w, cin, cout):
+            e.down_s = True
+            t1 = timeit(lambda: e.conv(op, x, relu=True, relu_from=rf))
+            print('%3dx%-3d %3d->%-3d (of %3d) x%d  generic %6.1f us   k_down_s %6.1f us (slab %d)' % (h, w, cin, cout, wide, cnt, t0, t1, e.lib.pam_conv3x3s2_slab(h, w, cin, cout)), flush=True)
+            continue
         line = '%3dx%-3d %3d->%-3d (of %3d) x%d  generic %6.1f us' % (h, w, cin, cout, wide, cnt, t0)
         if cin == 48:
             e.down48 = True
