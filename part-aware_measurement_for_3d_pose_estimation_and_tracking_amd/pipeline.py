@@ -67,7 +67,7 @@ class FramePipeline(object):
         self.pose_streams = [torch.cuda.Stream(self.device) for _ in range(pose_streams)] if pose_streams > 1 else None
         self._frame_no = 0
 
-    def _pick_track_stream(self, tries=8, spin_us=400):
+    def _pick_track_stream(self, tries=8, spin_us=400, avoid=None):
         """A stream for the exchange + tracker that REALLY runs beside the caller's (pose) stream.  HIP streams are multiplexed onto a few
         hardware queues (4 by default on ROCm 7.2) and a queue is in-order: the first stream the pool handed out sat on the pose stream's
         queue, so frame t's 80 us tracker kernel ran in FRONT of frame t + 1's crop kernel instead of under its conv stack (rocprofv3
@@ -76,7 +76,9 @@ class FramePipeline(object):
         queried, so this measures it: two spin kernels (pam_clock_probe, one wave each), one per stream, take as long as ONE when the
         queues differ and as long as two when they are the same.  Returns (stream, overlaps); the first candidate that overlaps wins.
         The reference point is the stream that is current when the pipeline is built (frames are issued on the caller's current stream);
-        with pose_streams = 2 the frames run on two pool streams of their own, which this does not test against."""
+        with pose_streams = 2 the frames run on two pool streams of their own, which this does not test against.
+        avoid: streams the new one must ALSO overlap with (the detector's stream must share a queue neither with the pose nor with the
+        tracker stream)."""
         import ctypes as C
         import time
         pose = torch.cuda.current_stream(self.device)
@@ -91,14 +93,52 @@ class FramePipeline(object):
                     raise _lib.PamError('pam_clock_probe failed')
             torch.cuda.synchronize(self.device)
             return time.perf_counter() - t0
+        others = [o for o in (avoid or []) if o is not None]
+
+        def pair(x, y, us):
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for st, o in ((x, out), (y, out[2:])):
+                if lib.pam_clock_probe(C.c_void_p(st.cuda_stream), C.c_void_p(o.data_ptr()), us) != 0:
+                    raise _lib.PamError('pam_clock_probe failed')
+            torch.cuda.synchronize(self.device)
+            return time.perf_counter() - t0
         cands = []
         for _ in range(tries):
             s = torch.cuda.Stream(self.device)
             cands.append(s)
             both(s, 20)                                  # first use: the stream gets its hardware queue here
-            if min(both(s, spin_us) for _ in range(3)) < 1.5e-6 * spin_us:
+            if min(both(s, spin_us) for _ in range(3)) < 1.5e-6 * spin_us and \
+                    all(min(pair(o, s, spin_us) for _ in range(3)) < 1.5e-6 * spin_us for o in others):
                 return s, True
         return cands[0], False
+
+    # -- person detector of frame t + 1 under the pose network of frame t -----------------------------------------------------------------
+    def attach_detector(self, detector):
+        """detector: a pam.yolov3.YOLOv3.  The reference loop is detect -> pose -> track per frame (/root/reference/src/testmodel.py:59-63,
+        ivclabpose.py:183-204); here frame t + 1's detection (k_resize_frames -> Darknet-53 -> k_yolo_detect, one hipGraph replay) is
+        issued on a stream and hardware queue of its own as soon as frame t's crop kernel has read the detector's previous output, and
+        runs under frame t's conv stack; frame t + 1's crop kernel waits (on the device) for it."""
+        self.detector = detector
+        self.det_stream, self.det_overlaps = self._pick_track_stream(avoid=[self.track_stream])
+        self.ev_det, self.ev_crop = [torch.cuda.Event(), torch.cuda.Event()], torch.cuda.Event()
+        self._det_frames = 0
+
+    def detect_ahead(self, frames):
+        """Issue the detection of the NEXT frame (frames: its (views, H, W, 3) uint8 BGR device tensor) behind the crop kernel that was
+        issued last on the current stream; returns (boxes, count) device tensors, valid once ``wait_detection`` of that frame has run."""
+        cur = torch.cuda.current_stream(self.device)
+        self.ev_crop.record(cur)
+        with torch.cuda.stream(self.det_stream):
+            self.det_stream.wait_event(self.ev_crop)
+            out = self.detector.detect_dev(frames)
+            self._det_frames += 1
+            self.ev_det[self._det_frames & 1].record(self.det_stream)
+        return out
+
+    def wait_detection(self):
+        """Order the current stream behind the latest detection issued by ``detect_ahead`` (call before the frame's crop kernel)."""
+        torch.cuda.current_stream(self.device).wait_event(self.ev_det[self._det_frames & 1])
 
     def stream_ptr(self):
         return torch.cuda.current_stream(self.device).cuda_stream
