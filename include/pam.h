@@ -180,6 +180,14 @@ int pam_head_decode_soft(void* stream, int n, int hm_h, int hm_w, const void* fe
 int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames /*dev array of n_views frame ptrs*/,
                          int frame_h, int frame_w, const int32_t* dev_view_of, const float* dev_boxes,
                          int out_h, int out_w, int out_c /*3, or 8 = RGB + 5 zero channels*/, void* dev_out_bf16);
+/* the same with (a) n_total >= n crops written: crops n .. n_total - 1 repeat crop n - 1 (a hipGraph replay captured for a bucket of
+ * n_total crops takes a call of n without a padded box table), and (b) antialias != 0: the resize of upstream simple-HRNet (a PIL image
+ * through torchvision's Resize, i.e. PIL's ImagingResample with the bilinear filter): taps = the frame pixels whose centres lie within
+ * max(scale, 1) of the output pixel's centre inside the box rounded outwards, triangle weights, normalised, in float32 (PIL's uint8
+ * rounding between its two passes is not reproduced).  Equal to the plain bilinear form wherever the box is not larger than the output. */
+int pam_preprocess_crops_ex(void* stream, int n, int n_total, const void* const* dev_frames, int frame_h, int frame_w,
+                            const int32_t* dev_view_of, const float* dev_boxes, int out_h, int out_w, int out_c, void* dev_out_bf16,
+                            int antialias);
 int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw, int hm_h, int hm_w,
                         const int32_t* dev_view_of, const int32_t* dev_slot_of, const float* dev_boxes,
                         int max_dets, double* dev_det, float* dev_kp_xyc /*optional n*17*3 (x,y,conf) or NULL*/);

@@ -62,6 +62,7 @@ _SIGS = {
     'pam_op_velocity': (_I, [_P, _I, _P, _P]),
     'pam_op_hyp_cost': (_I, [_P, _I, _P, _P, _I, _P, _P, _P]),
     'pam_preprocess_crops': (_I, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P]),
+    'pam_preprocess_crops_ex': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P, _I]),
     'pam_decode_heatmaps': (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P]),
     'pam_clock_probe': (_I, [_P, _P, _I]),
     'pam_conv2d_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P] + [_I] * 11),

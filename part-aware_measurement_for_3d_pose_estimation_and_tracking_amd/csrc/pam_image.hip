@@ -13,34 +13,71 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest
 
 // One thread per output pixel: bilinear sample (half-pixel centres, border replicate) of the person box from the BGR
 // uint8 frame, BGR->RGB, /255, ImageNet mean/std, bf16 NHWC store (6 B per thread, contiguous across the wave).
-__global__ __launch_bounds__(256) void k_preprocess_crops(int n, const uint8_t* const* __restrict__ frames, int H, int W,
+// antialias: the resize of upstream simple-HRNet (a PIL image through torchvision's Resize) filters with a triangle whose support grows
+// with the down-scaling factor; plain bilinear interpolation (the default here, = cv2.resize INTER_LINEAR / F.interpolate(bilinear)) only
+// ever reads 2 x 2 pixels.  The two agree for boxes no larger than the network input; HD boxes taller than 384 pixels are down-scaled.
+// With antialias the taps are the frame pixels i whose centres lie within max(scale, 1) of the output pixel's centre, inside the box
+// rounded outwards (the crop upstream cuts), weights 1 - |i + 0.5 - centre| / max(scale, 1), normalised (PIL's ImagingResample formula,
+// in float32: PIL's own uint8 rounding between its two passes is not reproduced).  Crops n_src .. (grid) repeat crop n_src - 1: a replay
+// bucket larger than the call (HRNetPose pads a batch to a multiple of graph_bucket) needs no padded box table.
+constexpr int AA_MAXT = 24;             // taps per axis at most (down-scaling by up to 11.5)
+__global__ __launch_bounds__(256) void k_preprocess_crops(int n_src, const uint8_t* const* __restrict__ frames, int H, int W,
                                                           const int* __restrict__ view_of, const float* __restrict__ boxes,
-                                                          int oh, int ow, int oc, uint16_t* __restrict__ out) {
-    const int crop = blockIdx.y;
+                                                          int oh, int ow, int oc, uint16_t* __restrict__ out, int antialias) {
+    const int crop = blockIdx.y, src = min(crop, n_src - 1);
     const int px = blockIdx.x * blockDim.x + threadIdx.x;
-    if (crop >= n || px >= oh * ow) return;
+    if (px >= oh * ow) return;
     const int oy = px / ow, ox = px % ow;
-    const uint8_t* __restrict__ img = frames[view_of[crop]];
-    const float bx = boxes[crop * 4 + 0], by = boxes[crop * 4 + 1], bw = boxes[crop * 4 + 2], bh = boxes[crop * 4 + 3];
-    float sx = bx + (ox + 0.5f) * (bw / (float)ow) - 0.5f;
-    float sy = by + (oy + 0.5f) * (bh / (float)oh) - 0.5f;
-    sx = fminf(fmaxf(sx, 0.0f), (float)(W - 1));
-    sy = fminf(fmaxf(sy, 0.0f), (float)(H - 1));
-    const int x0 = (int)sx, y0 = (int)sy;
-    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-    const float fx = sx - (float)x0, fy = sy - (float)y0;
-    const uint8_t* r0 = img + ((size_t)y0 * W) * 3;
-    const uint8_t* r1 = img + ((size_t)y1 * W) * 3;
+    const uint8_t* __restrict__ img = frames[view_of[src]];
+    const float bx = boxes[src * 4 + 0], by = boxes[src * 4 + 1], bw = boxes[src * 4 + 2], bh = boxes[src * 4 + 3];
     const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f};
     uint16_t o[3];
+    if (!antialias) {
+        float sx = bx + (ox + 0.5f) * (bw / (float)ow) - 0.5f;
+        float sy = by + (oy + 0.5f) * (bh / (float)oh) - 0.5f;
+        sx = fminf(fmaxf(sx, 0.0f), (float)(W - 1));
+        sy = fminf(fmaxf(sy, 0.0f), (float)(H - 1));
+        const int x0 = (int)sx, y0 = (int)sy;
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const float fx = sx - (float)x0, fy = sy - (float)y0;
+        const uint8_t* r0 = img + ((size_t)y0 * W) * 3;
+        const uint8_t* r1 = img + ((size_t)y1 * W) * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {          // c indexes RGB; source is BGR
-        const int sc = 2 - c;
-        const float a = (float)r0[x0 * 3 + sc], b = (float)r0[x1 * 3 + sc];
-        const float cc = (float)r1[x0 * 3 + sc], d = (float)r1[x1 * 3 + sc];
-        const float top = a + (b - a) * fx, bot = cc + (d - cc) * fx;
-        const float v = (top + (bot - top) * fy) * (1.0f / 255.0f);
-        o[c] = f32_to_bf16((v - mean[c]) * istd[c]);
+        for (int c = 0; c < 3; ++c) {          // c indexes RGB; source is BGR
+            const int sc = 2 - c;
+            const float a = (float)r0[x0 * 3 + sc], b = (float)r0[x1 * 3 + sc];
+            const float cc = (float)r1[x0 * 3 + sc], d = (float)r1[x1 * 3 + sc];
+            const float top = a + (b - a) * fx, bot = cc + (d - cc) * fx;
+            const float v = (top + (bot - top) * fy) * (1.0f / 255.0f);
+            o[c] = f32_to_bf16((v - mean[c]) * istd[c]);
+        }
+    } else {
+        const float scx = bw / (float)ow, scy = bh / (float)oh, supx = fmaxf(scx, 1.0f), supy = fmaxf(scy, 1.0f);
+        const float cx = bx + (ox + 0.5f) * scx, cy = by + (oy + 0.5f) * scy;
+        const int xlo = max(0, (int)floorf(bx)), xhi = max(xlo + 1, min(W, (int)ceilf(bx + bw)));
+        const int ylo = max(0, (int)floorf(by)), yhi = max(ylo + 1, min(H, (int)ceilf(by + bh)));
+        int x0 = max(xlo, (int)(cx - supx + 0.5f)), x1 = min(xhi, (int)(cx + supx + 0.5f));
+        int y0 = max(ylo, (int)(cy - supy + 0.5f)), y1 = min(yhi, (int)(cy + supy + 0.5f));
+        if (x1 <= x0) { x0 = min(max((int)cx, xlo), xhi - 1); x1 = x0 + 1; }
+        if (y1 <= y0) { y0 = min(max((int)cy, ylo), yhi - 1); y1 = y0 + 1; }
+        x1 = min(x1, x0 + AA_MAXT); y1 = min(y1, y0 + AA_MAXT);
+        const float isx = 1.0f / supx, isy = 1.0f / supy;
+        float acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f;
+        for (int y = y0; y < y1; ++y) {
+            const float wy = fmaxf(0.0f, 1.0f - fabsf(((float)y + 0.5f - cy) * isy));
+            const uint8_t* r = img + ((size_t)y * W) * 3;
+            float row[3] = {0.f, 0.f, 0.f}, wr = 0.f;
+            for (int x = x0; x < x1; ++x) {
+                const float wx = fmaxf(0.0f, 1.0f - fabsf(((float)x + 0.5f - cx) * isx));
+                row[0] += wx * (float)r[x * 3 + 2]; row[1] += wx * (float)r[x * 3 + 1]; row[2] += wx * (float)r[x * 3 + 0];
+                wr += wx;
+            }
+            acc[0] += wy * row[0]; acc[1] += wy * row[1]; acc[2] += wy * row[2];
+            wsum += wy * wr;
+        }
+        const float inv = wsum > 0.f ? 1.0f / (wsum * 255.0f) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = f32_to_bf16((acc[c] * inv - mean[c]) * istd[c]);
     }
     if (oc == 3) {
         uint16_t* dst = out + (((size_t)crop * oh + oy) * ow + ox) * 3;
@@ -381,15 +418,20 @@ extern "C" int pam_head_decode_soft(void* stream, int n, int hm_h, int hm_w, con
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 
+extern "C" int pam_preprocess_crops_ex(void* stream, int n, int n_total, const void* const* dev_frames, int frame_h, int frame_w,
+                                       const int32_t* dev_view_of, const float* dev_boxes, int out_h, int out_w,
+                                       int out_c, void* dev_out_bf16, int antialias) {
+    if (n < 0 || n_total < n || !dev_frames || !dev_view_of || !dev_boxes || !dev_out_bf16 || out_h <= 0 || out_w <= 0 || (out_c != 3 && out_c != 8)) return PAM_E_ARG;
+    if (n == 0) return PAM_OK;
+    dim3 grid((out_h * out_w + 255) / 256, n_total);
+    hipLaunchKernelGGL(k_preprocess_crops, grid, dim3(256), 0, (hipStream_t)stream, n, (const uint8_t* const*)dev_frames,
+                       frame_h, frame_w, dev_view_of, dev_boxes, out_h, out_w, out_c, (uint16_t*)dev_out_bf16, antialias ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
 extern "C" int pam_preprocess_crops(void* stream, int n, const void* const* dev_frames, int frame_h, int frame_w,
                                     const int32_t* dev_view_of, const float* dev_boxes, int out_h, int out_w,
                                     int out_c, void* dev_out_bf16) {
-    if (n < 0 || !dev_frames || !dev_view_of || !dev_boxes || !dev_out_bf16 || out_h <= 0 || out_w <= 0 || (out_c != 3 && out_c != 8)) return PAM_E_ARG;
-    if (n == 0) return PAM_OK;
-    dim3 grid((out_h * out_w + 255) / 256, n);
-    hipLaunchKernelGGL(k_preprocess_crops, grid, dim3(256), 0, (hipStream_t)stream, n, (const uint8_t* const*)dev_frames,
-                       frame_h, frame_w, dev_view_of, dev_boxes, out_h, out_w, out_c, (uint16_t*)dev_out_bf16);
-    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+    return pam_preprocess_crops_ex(stream, n, n, dev_frames, frame_h, frame_w, dev_view_of, dev_boxes, out_h, out_w, out_c, dev_out_bf16, 0);
 }
 
 extern "C" int pam_decode_heatmaps(void* stream, int n, const float* dev_heatmaps, int nchw, int hm_h, int hm_w,

@@ -267,7 +267,7 @@ class HRNetPose(object):
 
     def __init__(self, c, nof_joints, checkpoint_path, model_name='HRNet', resolution=(384, 288), hrpose_args=None,
                  device=0, dtype=torch.bfloat16, use_graph=True, seed=0, max_dets=16, backend='hip', graph_bucket=4,
-                 shard_crops=False, group=None, autotune=False, max_crops=32):
+                 shard_crops=False, group=None, autotune=False, max_crops=32, antialias=False):
         assert model_name == 'HRNet' and int(nof_joints) == 17
         if not torch.cuda.is_available():
             raise RuntimeError('HRNetPose needs a GPU (the preprocessing / decode kernels are HIP only; no CPU fallback)')
@@ -315,6 +315,11 @@ class HRNetPose(object):
         self.in_channels = 8
         self.model = None
         self.use_graph = use_graph
+        # crop resize: False = plain bilinear (cv2.resize INTER_LINEAR semantics; the default: exact for boxes up to the network input, and what
+        # every golden of this repository was made with); True = upstream simple-HRNet's PIL / torchvision Resize, which filters with a triangle
+        # that widens with the down-scaling factor (HD Panoptic boxes taller than 384 pixels) -- csrc/pam_image.hip
+        self.antialias = bool(antialias)
+        self.captures = 0            # hipGraph captures made so far (a capture inside a frame is a stall of hundreds of ms: warm())
         # predict() pads a batch to the next multiple of graph_bucket crops (repeating its last box; the padded rows are not
         # decoded): a sequence whose person count wanders then replays a handful of captured graphs instead of capturing one
         # per count (a capture is a multi-100-ms stall); 1 = exact batch sizes
@@ -391,6 +396,7 @@ class HRNetPose(object):
                 graph = _lib.new_graph()
                 with torch.cuda.graph(graph, pool=self._pool_of(slot)):
                     static_out = self._forward(static_in, kind)
+                self.captures += 1
             self.hip.arena = None
             g = (graph, static_in, static_out)
             self._graphs[(n, kind, slot)] = g
@@ -416,13 +422,40 @@ class HRNetPose(object):
         ar = self._arenas.get(slot)
         need = n * self._arena_bytes_per_crop
         if ar is None or ar.half_bytes < need:
-            # first arena: max_crops crops.  A forward beyond that gets a new arena of TWICE its need (the captures made so far keep the
-            # old one: their kernels hold its addresses, and a captured graph is never destroyed, _lib.new_graph), so a crop count that
-            # creeps upwards costs at most 4 x the largest forward's need in total; a caller that knows its largest forward says so
-            # (max_crops: FramePipeline passes views x max_dets, predict() its batch_size) and gets exactly one arena
-            ar = ActivationArena(self.device, max(need, self.max_crops * self._arena_bytes_per_crop) if ar is None else 2 * need)
+            # first arena: twice the first forward's need, at most max_crops crops (a rig of 31 views x 16 detections would otherwise
+            # reserve 18 GB per replay slot for frames of 40 crops); warm() captures its largest bucket first and so sizes the arena once.
+            # A forward beyond the arena gets a new one of TWICE its need (the captures made so far keep the old one: their kernels hold
+            # its addresses, and a captured graph is never destroyed, _lib.new_graph): a crop count that creeps upwards costs at most
+            # 4 x the largest forward's need in total
+            cap = self.max_crops * self._arena_bytes_per_crop
+            ar = ActivationArena(self.device, max(need, min(2 * need, cap)) if ar is None else 2 * need)
             self._arenas[slot] = ar
         return ar
+
+    def bucket(self, n, cap=None):
+        """Crop count of the replay that serves a call of n crops: the next multiple of graph_bucket (at most cap)."""
+        b = self.graph_bucket
+        m = (n + b - 1) // b * b
+        return min(m, cap) if cap is not None and cap >= n else m
+
+    def warm(self, max_crops, slots=(0,), kind='features'):
+        """Capture the replay of every crop-count bucket up to max_crops NOW (largest first: one activation arena, sized once), so that
+        no frame pays a capture later -- the first sight of a bucket inside a frame is a stall of hundreds of milliseconds.
+        -> dict(buckets, captures, seconds, arena_bytes): what the prewarmed cache holds."""
+        import time
+        t0, c0 = time.perf_counter(), self.captures
+        buckets = sorted({self.bucket(k) for k in range(1, int(max_crops) + 1)}, reverse=True)
+        self.max_crops = max(self.max_crops, buckets[0] if buckets else 0)
+        for slot in slots:
+            for n in buckets:
+                if (n, kind, slot) not in self._graphs:
+                    self._run(self.input_buffer(n, slot), kind, slot)
+        torch.cuda.synchronize(self.device)
+        return dict(buckets=sorted(buckets), captures=self.captures - c0, seconds=time.perf_counter() - t0, arena_bytes=self.arena_bytes())
+
+    def arena_bytes(self):
+        """Device memory of the activation arenas of all replay slots."""
+        return int(sum(2 * a.half_bytes for a in self._arenas.values()))
 
     def _pool_of(self, slot):
         if slot not in self._pools:
@@ -451,12 +484,14 @@ class HRNetPose(object):
 
     # -- HIP kernels around it -----------------------------------------------------------------------------------------
     def preprocess(self, frame_ptrs, frame_h, frame_w, view_of, boxes, out):
-        """frame_ptrs: int64 device tensor of per-view frame addresses; view_of int32 (N), boxes float32 (N,4) xywh."""
+        """frame_ptrs: int64 device tensor of per-view frame addresses; view_of int32 (N), boxes float32 (N,4) xywh.  out may hold more
+        crops than N (a replay bucket): the extra ones repeat the last crop."""
         H, W = self.resolution
         st = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.pam_preprocess_crops(C.c_void_p(st), int(view_of.numel()), C.c_void_p(frame_ptrs.data_ptr()),
-                                           int(frame_h), int(frame_w), C.c_void_p(view_of.data_ptr()),
-                                           C.c_void_p(boxes.data_ptr()), H, W, int(out.shape[1]), C.c_void_p(out.data_ptr()))
+        rc = self.lib.pam_preprocess_crops_ex(C.c_void_p(st), int(view_of.numel()), int(out.shape[0]), C.c_void_p(frame_ptrs.data_ptr()),
+                                              int(frame_h), int(frame_w), C.c_void_p(view_of.data_ptr()),
+                                              C.c_void_p(boxes.data_ptr()), H, W, int(out.shape[1]), C.c_void_p(out.data_ptr()),
+                                              1 if self.antialias else 0)
         if rc != 0:
             raise _lib.PamError('pam_preprocess_crops failed: %d' % rc)
 
@@ -564,11 +599,8 @@ class HRNetPose(object):
             e = min(hi, s + batch_size)
             k = e - s
             mp = min(batch_size, (k + self.graph_bucket - 1) // self.graph_bucket * self.graph_bucket) if batch_size >= self.graph_bucket else k
-            vo, bb = view_of[s:e], bx[s:e]
-            if mp > k:                                   # pad with copies of the last crop
-                vo = torch.cat([vo, vo[-1:].expand(mp - k)]); bb = torch.cat([bb, bb[-1:].expand(mp - k, 4)])
-            x = self.input_buffer(mp)
-            self.preprocess(ptrs, fh, fw, vo.contiguous(), bb.contiguous(), x)
+            x = self.input_buffer(mp)                    # mp > k: the crop kernel repeats the last crop into the bucket's spare rows
+            self.preprocess(ptrs, fh, fw, view_of[s:e], bx[s:e], x)
             self.head_decode(self.features(x), view_of[s:e], slot_of[s:e], bx[s:e], det, kp[s:e], n=k)
         if self.world > 1:
             from .distributed import gather_crop_keypoints

@@ -930,7 +930,11 @@ class HipHRNet(ConvEngine):
     def _head(self, x8):
         """stem + layer1: one dependent chain on the caller's stream -> the (N, 256, H/4, W/4) tensor the branches start from"""
         self._epoch()
-        if self.fuse_stem and self.fuse_tail and self.stop_after != 'stem':
+        n8, _, h8, w8 = x8.shape
+        # the fused kernels index with 32 bits: > 606 crops of 384 x 288 (N H W 512 >= 2^31 at a quarter of the resolution) take the
+        # un-fused launches, which address with 64 bits
+        small = n8 * ((h8 + 3) // 4) * ((w8 + 3) // 4) * 512 < 2 ** 31 and n8 * h8 * w8 * 16 < 2 ** 31
+        if self.fuse_stem and self.fuse_tail and self.stop_after != 'stem' and small:
             x0, y = self.stem_fused(self.stem, x8)
         else:
             x = self.conv(self.conv1, x8, relu=True)
@@ -945,7 +949,7 @@ class HipHRNet(ConvEngine):
             if y is None:
                 y = self.pointwise64(self.pw0, x0)
             for i, b in enumerate(self.layer1):
-                if self.fuse_bneck and (i > 0 or self.fuse_bneck0):
+                if self.fuse_bneck and small and (i > 0 or self.fuse_bneck0):
                     x, y = self.bottleneck_fused(self.bnecks[i], y, res, x0 if i == 0 else None)
                 else:
                     y2 = self.conv(b['c2'], y, relu=True)

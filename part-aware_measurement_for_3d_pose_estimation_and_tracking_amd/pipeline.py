@@ -19,7 +19,7 @@ NUM_JOINTS = 17
 class FramePipeline(object):
     def __init__(self, calib_cameras, matcher, conf_threshold, frame_hw, max_dets=8, max_tracks=16, device=0, world=1,
                  rank=0, group=None, use_graph=True, hrnet=True, seed=0, shard='views', overlap_tracker=False, net=None, exchange='torch',
-                 pose_streams=1, autotune=True):
+                 pose_streams=1, autotune=True, prewarm=False):
         """shard: 'views' -- rank owns whole camera views (pose_step / track_step take view-local inputs); 'crops' -- the
         frame's crops are dealt out evenly over the ranks (pose_step_crops / track_step_crops take global view indices).
         overlap_tracker (either mode): exchange + tracker kernel + fetch of frame t run on their own stream, under the conv
@@ -28,7 +28,10 @@ class FramePipeline(object):
         replay instance (static input, activations, output) of the same weights, so frame t+1's HBM-bound stem / layer1 runs beside
         frame t's CU-bound last stages.  Frames still finish in order (the tracker stream takes them in order).
         autotune: the conv stack's replay of every crop count is the fastest of the executor's configurations on this device
-        (HRNetPose(autotune=True))."""
+        (HRNetPose(autotune=True)).
+        prewarm: capture the replay of every crop-count bucket this rank can see (its views x max_dets, in steps of the network's
+        graph_bucket) at construction -- `self.warmed` says what that cost -- and pad every frame's forward to its bucket, so that no
+        step() ever captures (the reference's call shape has a fixed batch_size = 20, /root/reference/src/ivclabpose.py:208-212)."""
         self.device = torch.device('cuda:%d' % device)
         torch.cuda.set_device(self.device)
         self.cams = calib_cameras
@@ -66,6 +69,12 @@ class FramePipeline(object):
         assert pose_streams in (1, 2) and (pose_streams == 1 or overlap_tracker), 'two pose streams need the tracker on its own stream'
         self.pose_streams = [torch.cuda.Stream(self.device) for _ in range(pose_streams)] if pose_streams > 1 else None
         self._frame_no = 0
+        self.bucketed, self.warmed = bool(prewarm), None
+        if prewarm and self.net is not None:
+            most = (self.C if shard == 'crops' else len(self.mine)) * max_dets
+            if shard == 'crops' and world > 1:
+                most = (most + world - 1) // world
+            self.warmed = self.net.warm(most, slots=(0, 1) if pose_streams > 1 else (0,))
 
     def _pick_track_stream(self, tries=8, spin_us=400, avoid=None):
         """A stream for the exchange + tracker that REALLY runs beside the caller's (pose) stream.  HIP streams are multiplexed onto a few
@@ -147,7 +156,7 @@ class FramePipeline(object):
         """crop -> conv stack -> head + arg-max for one frame on the current stream, replay slot = frame parity when two pose streams run."""
         k = (self._frame_no & 1) if self.pose_streams is not None else 0
         n = int(views.numel())
-        x = self.net.input_buffer(n, k)
+        x = self.net.input_buffer(self.net.bucket(n) if self.bucketed else n, k)     # a bucket's spare rows repeat the last crop, undecoded
         self.net.preprocess(frame_ptrs, self.frame_h, self.frame_w, views, boxes, x)
         if after_crop is not None:
             after_crop()                                # the frames have been read: a feeder may mark its buffers reusable here
@@ -157,7 +166,7 @@ class FramePipeline(object):
         if time_events is not None:
             time_events[1].record(torch.cuda.current_stream(self.device))
         self.wait_track()                               # the previous frame's exchange / tracker read the buffer decode writes
-        self.net.head_decode(f, views, slot_of, boxes, det)
+        self.net.head_decode(f, views, slot_of, boxes, det, n=n)
 
     @contextlib.contextmanager
     def frame(self):

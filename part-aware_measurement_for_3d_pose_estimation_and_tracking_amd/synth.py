@@ -71,13 +71,16 @@ def _pose_world(center, heading, jitter):
 
 def make_sequence(size='S2', n_frames=303, seed=0, noise_px=1.5, outlier_p=0.05,
                   occlusion_every=50, empty_view_every=37, birth_death_frame=100, shuffle=True,
-                  blank_frames=()):
+                  blank_frames=(), churn_every=0, churn_len=0):
     """Synthetic sequence.  Returns dict with
        'calib'   : {'P','K','RT'}
        'frames'  : list over frames of list over views of (n,17,3) float64 arrays in the HRNet dump
                    layout (x, y, score) (n may be 0)
        'gt3d'    : list over frames of dict person_id -> (17,3) world joints
        'meta'    : size parameters
+    churn_every / churn_len (round 5, the longer S3 / S4 golden traces): person (t // churn_every) % P is invisible in EVERY view during the
+    first churn_len frames of each period of churn_every frames -- its track dies (max_age) and a new one is born when it comes back, so
+    a trace sees a death and a birth every period instead of once per sequence.  0 = off (the random stream is then unchanged).
     """
     cfg = SIZES[size]
     C, Pn, w, h, f = cfg['C'], cfg['P'], cfg['w'], cfg['h'], cfg['f']
@@ -116,6 +119,8 @@ def make_sequence(size='S2', n_frames=303, seed=0, noise_px=1.5, outlier_p=0.05,
                     a = rng.uniform(0, 2 * np.pi); r = rng.uniform(80, 200)
                     xy[j] += r * np.array([np.cos(a), np.sin(a)])
                 if c == empty_view or (c == occl[0] and k == occl[1]) or t in blank_frames:
+                    continue
+                if churn_every and t >= churn_every and (t % churn_every) < churn_len and p == (t // churn_every) % Pn:
                     continue
                 dets.append(np.concatenate([xy, sc[:, None]], axis=1))
             if shuffle and len(dets) > 1:

@@ -562,3 +562,51 @@ def test_configuration_follows_the_crop_count_and_stays_consistent():
     x20.copy_(torch.randn(x20.shape, device=x20.device).to(x20.dtype)); x20[:, 3:] = 0
     b.features(x20); torch.cuda.synchronize()
     assert b.tuned[20]['choice'] == 'fused48_fused96' and set(c['choice'] for c in b.tuned.values()) <= set(hrnet_hip.HipHRNet.CONFIGS)
+
+
+def test_preprocess_bucket_padding_repeats_the_last_crop(net):
+    """A replay bucket larger than the call: the crop kernel fills the spare rows with the last crop (no padded box table on the host)."""
+    dev = net.device
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randint(0, 256, (2, 288, 360, 3), dtype=torch.uint8, generator=g).to(dev)
+    ptrs = torch.tensor([frames[i].data_ptr() for i in range(2)], dtype=torch.int64, device=dev)
+    view_of = torch.tensor([0, 1, 1], dtype=torch.int32, device=dev)
+    boxes = torch.tensor([[10, 20, 100, 200], [30, 40, 120, 160], [200, 100, 90, 120]], dtype=torch.float32, device=dev)
+    x3, x8 = net.input_buffer(3).clone(), net.input_buffer(8).clone()
+    net.preprocess(ptrs, 288, 360, view_of, boxes, x3)
+    net.preprocess(ptrs, 288, 360, view_of, boxes, x8)
+    torch.cuda.synchronize()
+    assert torch.equal(x8[:3], x3) and all(torch.equal(x8[k], x3[2]) for k in range(3, 8))
+
+
+def test_preprocess_antialias_matches_the_pil_formula(net):
+    """The optional resize of upstream simple-HRNet (PIL image through torchvision Resize): support-scaled triangle filter.  Checked
+    against torch's antialiased bilinear interpolation of the integer-aligned crop (the same ImagingResample formula in float32), for
+    boxes that are down-scaled (HD frames), up-scaled, and mixed; and equal to the plain bilinear form where nothing is down-scaled."""
+    import torch.nn.functional as F
+    from pam import hrnet
+    dev = net.device
+    g = torch.Generator().manual_seed(6)
+    frames = torch.randint(0, 256, (2, 1080, 1920, 3), dtype=torch.uint8, generator=g).to(dev)
+    ptrs = torch.tensor([frames[i].data_ptr() for i in range(2)], dtype=torch.int64, device=dev)
+    view_of = torch.tensor([0, 1, 0, 1], dtype=torch.int32, device=dev)
+    boxes = torch.tensor([[100, 50, 600, 900], [700, 0, 432, 1080], [400, 300, 150, 200], [1500, 600, 400, 300]], dtype=torch.float32, device=dev)
+    aa = hrnet.HRNetPose(48, 17, None, use_graph=False, antialias=True)
+    x, xp = net.input_buffer(4).clone(), net.input_buffer(4).clone()
+    aa.preprocess(ptrs, 1080, 1920, view_of, boxes, x)
+    net.preprocess(ptrs, 1080, 1920, view_of, boxes, xp)
+    torch.cuda.synchronize()
+    mean = torch.tensor([0.485, 0.456, 0.406], device=dev).view(1, 3, 1, 1); std = torch.tensor([0.229, 0.224, 0.225], device=dev).view(1, 3, 1, 1)
+    for i in range(4):
+        bx, by, bw, bh = [int(v) for v in boxes[i].tolist()]
+        crop = frames[int(view_of[i]), by:by + bh, bx:bx + bw].permute(2, 0, 1)[[2, 1, 0]].float().unsqueeze(0)      # BGR -> RGB
+        ref = (F.interpolate(crop, size=(384, 288), mode='bilinear', antialias=True, align_corners=False) / 255.0 - mean) / std
+        err = (x[i:i + 1, :3].float() - ref).abs().max().item()
+        assert err <= 2.0 ** -7 * 2.7 + 2e-2, (i, err)
+        down = bw > 288 or bh > 384
+        d = (x[i, :, 4:-4, 4:-4].float() - xp[i, :, 4:-4, 4:-4].float()).abs().max().item()
+        # where nothing is down-scaled the two modes are the same interpolation in the crop's interior (to a bf16 rounding: another
+        # evaluation order; at the crop's border the plain form reads the frame pixels just outside the box, the PIL form -- which resizes
+        # the cut-out crop -- does not); a down-scaled box of random pixels is visibly smoother
+        assert (d > 0.2) if down else (d <= 2.0 ** -7 * 2.7 + 1e-3), (i, down, d)
+    assert float(x[:, 3:].float().abs().max()) == 0.0

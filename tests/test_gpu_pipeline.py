@@ -193,3 +193,48 @@ def test_view_records_in_place_match_packed_input():
         assert np.array_equal(a.out_i.numpy(), b.out_i.numpy())
         k = a.handle.layout.dbl_hdr_words
         assert np.array_equal(a.out_d.numpy()[:, k:], b.out_d.numpy()[:, k:])
+
+
+def test_prewarmed_pipeline_never_captures_inside_a_step():
+    """FramePipeline(prewarm=True) captures the replay of every crop-count bucket of its rig at construction; afterwards frames with any
+    number of crops run without a capture (HRNetPose.captures does not move), padded to their bucket by the crop kernel, and the records
+    equal the un-bucketed pipeline's.  Prints what the warm cache costs (arena bytes, seconds)."""
+    from pam import synth
+    from pam.distributed import CropGather
+    from pam.pipeline import FramePipeline
+    seq, cams, cfg, conf, meta = _rig('S1')
+    C, md = meta['C'], 4
+    n_det_all, det_all = synth.pack_frames(seq['frames'], md)
+    warm = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, shard='crops', prewarm=True, autotune=False)
+    w = warm.warmed
+    print('prewarm: buckets %s, %d captures in %.1f s, arena %.2f GiB' % (w['buckets'], w['captures'], w['seconds'], w['arena_bytes'] / 2 ** 30))
+    assert w['buckets'] == [4, 8, 12] and w['captures'] == 3 and w['arena_bytes'] == warm.net.arena_bytes() > 0
+    from pam import hrnet
+    exact = hrnet.HRNetPose(48, 17, None, use_graph=False, max_dets=md)                # the same weights (seed 0), forwards of exactly n crops
+    plain = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, shard='crops', net=exact)
+    dev = warm.device
+    g = torch.Generator().manual_seed(11)
+    frames = [torch.randint(0, 256, (meta['h'], meta['w'], 3), dtype=torch.uint8, generator=g).to(dev) for _ in range(C)]
+    ptrs = torch.tensor([f.data_ptr() for f in frames], dtype=torch.int64, device=dev)
+    c0 = warm.net.captures
+    seen = set()
+    for t in range(24):
+        vl, sl, bx = [], [], []
+        for v in range(C):
+            for s, kp in enumerate(seq['frames'][t][v][:((t + 2 * v) % (md + 1))]):   # 0 .. 3 persons per view, another mix every frame
+                x0, y0, x1, y1 = kp[:, 0].min(), kp[:, 1].min(), kp[:, 0].max(), kp[:, 1].max()
+                vl.append(v); sl.append(s); bx.append([x0, y0, max(x1 - x0, 8.0), max(y1 - y0, 8.0)])
+        if not vl:
+            continue
+        seen.add(len(vl))
+        tv = torch.tensor(vl, dtype=torch.int32, device=dev); ts = torch.tensor(sl, dtype=torch.int32, device=dev)
+        tb = torch.tensor(bx, dtype=torch.float32, device=dev).reshape(-1, 4)
+        warm.crop_gather.send.zero_()
+        warm.pose_step_crops(ptrs, tv, ts, tb)
+        assert warm.net.captures == c0, (t, len(vl))                                   # no capture inside a step
+        a = warm.crop_gather.send.clone()
+        plain.crop_gather.send.zero_()
+        plain.pose_step_crops(ptrs, tv, ts, tb)                                        # un-bucketed: a forward of exactly len(vl) crops
+        torch.cuda.synchronize()
+        assert torch.equal(a, plain.crop_gather.send), t
+    assert len(seen) >= 4, seen

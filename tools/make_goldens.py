@@ -427,8 +427,9 @@ def main():
     plans = [
         ('S1', 160, 0, dict(blank_frames=(60,))),
         ('S2', 160, 0, {}),
-        ('S3', 70, 1, dict(birth_death_frame=30, occlusion_every=20, empty_view_every=13, blank_frames=(40, 41))),
-        ('S4', 24, 2, dict(birth_death_frame=12, occlusion_every=6, empty_view_every=7)),
+        # round 5: the two hardest rigs at >= 80 frames with a track death + a birth every 22 / 20 frames (churn: one person invisible for 12 frames > MAX_AGE), denser occlusions, empty views and blank frames
+        ('S3', 132, 1, dict(birth_death_frame=30, occlusion_every=9, empty_view_every=7, blank_frames=(40, 41, 77), churn_every=22, churn_len=12)),
+        ('S4', 100, 2, dict(birth_death_frame=12, occlusion_every=5, empty_view_every=4, blank_frames=(33,), churn_every=20, churn_len=12)),
     ]
     for size, nf, seed, kw in plans:
         REC.clear()
