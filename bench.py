@@ -376,7 +376,7 @@ def full_pipeline_runs(torch, dist, pipe, inp, K, W, C, fh, fw, dev, ref_tracks)
     buf.copy_(frames)
     ptrs = torch.tensor([buf[v].data_ptr() for v in range(C)], dtype=torch.int64, device=dev)
     pf = inp['per_frame']
-    pipe.attach_detector(det)
+    pipe.attach_detector(det, frames=buf, n_crops=int(np.median([c for c in inp['local_crops'] if c > 0])))
     # the detector alone: one replay between HIP events (median of 20), FLOPs from a shape walk of its 75 convolutions
     det.net.count = dict(bytes=0, flops=0, launches=0)
     H, Wn = det.size
@@ -414,7 +414,7 @@ def full_pipeline_runs(torch, dist, pipe, inp, K, W, C, fh, fw, dev, ref_tracks)
     over = run(True)
     base_ms = None
     return {'value': over['value'], 'ms_per_step': over['ms_per_step'], 'serial': serial, 'overlapped': over,
-            'detector_stream_on_its_own_hw_queue': bool(pipe.det_overlaps),
+            'detector_stream_on_its_own_hw_queue': bool(pipe.det_overlaps), 'detector_stream_pick': pipe.det_pick,
             'detector': {'kernel': 'k_resize_frames + Darknet-53 (k_conv_stem / k_conv3x3 / k_conv_igemm, leaky + shortcut epilogues) + k_upsample_concat + k_yolo_detect: '
                                    'one hipGraph replay, %d launches, %d views %dx%d -> %dx%d, random weights' % (dlaunch, C, fw, fh, Wn, H),
                          'bound': 'mfma', 'ms': det_ms, 'flops': dflops, 'achieved': dflops / (det_ms * 1e-3) / 1e12, 'peak': MFMA_BF16_PEAK_TFLOPS,

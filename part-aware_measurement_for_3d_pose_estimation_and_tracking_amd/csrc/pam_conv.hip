@@ -1172,8 +1172,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_gs(ConvArgs a) {
                 uint32_t ov[2 * NTW];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
+                    if (a.relu == 2) {                                                       // Darknet's leaky ReLU (slope 0.1), epi_act1's arithmetic; round 5
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] = acc[i][j][r] > 0.0f ? acc[i][j][r] : 0.1f * acc[i][j][r];
+                    }
                     ov[2 * j] = pack_bf16x2(acc[i][j][0], acc[i][j][1]); ov[2 * j + 1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                    if (a.relu && n0 + g * 4 * NTW + j * 4 >= a.relu_from) {
+                    if (a.relu == 1 && n0 + g * 4 * NTW + j * 4 >= a.relu_from) {
                         ov[2 * j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j]), (s16x2){0, 0}));
                         ov[2 * j + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j + 1]), (s16x2){0, 0}));
                     }
@@ -1408,7 +1412,13 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     }
     if (tile_cfg >= 100) tile_cfg = -1;
     // streamed implicit GEMM (k_conv_gs): codes 0 / 1, taps in a 32-bit mask, whole 16-byte pieces per tap (Cin % 8 == 0)
-    const bool gs_ok = relu <= 1 && KH * KW <= 9 && Cin % 8 == 0 && (size_t)N * H * W * in_cstride * 2 < (1u << 31);
+    // (round 5: code 2 -- leaky, no residual -- too: the detector's 1x1 and strided layers, which the classic implicit GEMM ran at 20 us each)
+    const bool leaky_gs = relu == 2 && !a.res && classic && relu_from == 0;
+    const bool gs_ok = (relu <= 1 || leaky_gs) && KH * KW <= 9 && Cin % 8 == 0 && (size_t)N * H * W * in_cstride * 2 < (1u << 31);
+    if (leaky_gs && gs_ok && tile_cfg == -1 && conv_gs_auto(a)) {
+        CONV_KIND(PAM_CONV_KERNEL_GS);
+        return (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
+    }
     if (tile_cfg >= 8 && tile_cfg <= 12 && !gs_ok) return PAM_E_ARG;
     if (tile_cfg == 12) {                               // 64-pixel tiles: the smallest images (12 x 9) as a few hundred short workgroups
         if (a.res || Cout % 48 != 0) return PAM_E_ARG;

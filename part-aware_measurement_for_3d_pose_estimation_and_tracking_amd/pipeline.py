@@ -123,13 +123,41 @@ class FramePipeline(object):
         return cands[0], False
 
     # -- person detector of frame t + 1 under the pose network of frame t -----------------------------------------------------------------
-    def attach_detector(self, detector):
+    def attach_detector(self, detector, frames=None, n_crops=None, candidates=6):
         """detector: a pam.yolov3.YOLOv3.  The reference loop is detect -> pose -> track per frame (/root/reference/src/testmodel.py:59-63,
         ivclabpose.py:183-204); here frame t + 1's detection (k_resize_frames -> Darknet-53 -> k_yolo_detect, one hipGraph replay) is
         issued on a stream and hardware queue of its own as soon as frame t's crop kernel has read the detector's previous output, and
-        runs under frame t's conv stack; frame t + 1's crop kernel waits (on the device) for it."""
+        runs under frame t's conv stack; frame t + 1's crop kernel waits (on the device) for it.
+        frames + n_crops: choose the detector's stream by MEASUREMENT -- four hardware queues serve all streams and the pose replay's
+        own branch chains sit on all of them, so which queue the detector shares decides how much of it hides: `candidates` fresh
+        streams are each timed running the detector's replay beside the n_crops pose replay, the fastest pair wins (``det_pick``)."""
+        import time
         self.detector = detector
         self.det_stream, self.det_overlaps = self._pick_track_stream(avoid=[self.track_stream])
+        self.det_pick = None
+        if frames is not None and n_crops and self.net is not None:
+            cur = torch.cuda.current_stream(self.device)
+            x = self.net.input_buffer(int(n_crops))
+            self.net.features(x); detector.detect_dev(frames)
+            torch.cuda.synchronize(self.device)
+
+            def both(st, reps=6):
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    self.net.features(x)
+                    with torch.cuda.stream(st):
+                        detector.detect_dev(frames)
+                torch.cuda.synchronize(self.device)
+                return (time.perf_counter() - t0) / reps
+            cands = [self.det_stream] + [torch.cuda.Stream(self.device) for _ in range(candidates - 1)]
+            times = []
+            for st in cands:
+                both(st, 2)
+                times.append(min(both(st) for _ in range(2)))
+            k = int(np.argmin(times))
+            self.det_stream = cands[k]
+            self.det_pick = {'ms_pose_and_detector_side_by_side': [float(t * 1e3) for t in times], 'chosen': k}
         self.ev_det, self.ev_crop = [torch.cuda.Event(), torch.cuda.Event()], torch.cuda.Event()
         self._det_frames = 0
 

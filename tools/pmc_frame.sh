@@ -1,8 +1,9 @@
 #!/bin/bash
-# rocprofv3 PMC passes over k_frame (the fused matching / triangulation / tracking kernel): S2 x 1 scene, S4 x 1 scene, S2 x 2048 scenes.
+# rocprofv3 PMC passes over k_frame (the fused matching / triangulation / tracking kernel): one scene of every BASELINE workload (S1 Campus-like
+# 3 cams, S2 Shelf-like 5 cams, S3 Panoptic-like 5 HD cams, S4 Panoptic 31 cams) and S2 x 2048 scenes.
 # Counters in their own runs (no tracing), the program directly behind `--`.  -> gpurun_out/pmc_frame/<TAG>_pmc_k_frame.json
 # usage (GPU box, through gpurun): tools/pmc_frame.sh <git commit> [round tag]
-COMMIT=${1:-unknown}; TAG=${2:-r04}
+COMMIT=${1:-unknown}; TAG=${2:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_frame; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
@@ -10,7 +11,7 @@ P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INST
 P3="FETCH_SIZE"
 P4="WRITE_SIZE GRBM_GUI_ACTIVE"
 P5="TCC_HIT_sum TCC_MISS_sum"
-CASES=("S2 1" "S4 1" "S2 2048")
+CASES=("S1 1" "S2 1" "S3 1" "S4 1" "S2 2048")
 for CASE in "${CASES[@]}"; do
   set -- $CASE; SZ=$1; SC=$2; NAME=${SZ}_x${SC}
   python3 $GRAFT_REPO_ROOT/tools/frame_one.py --size $SZ --scenes $SC > $OUT/$NAME.plain.json 2> $OUT/$NAME.plain.err
@@ -23,7 +24,7 @@ done
 python3 - <<PY
 import csv, glob, json, collections
 out={'git_commit':'$COMMIT','how':'tools/pmc_frame.sh: rocprofv3 --pmc in 5 separate passes per case (SQ x2, FETCH_SIZE, WRITE_SIZE+GRBM, TCC hit/miss), program = tools/frame_one.py directly behind --; 32 launches per pass, the first 20 (track build-up) dropped, per-launch means over the last 12; launch time and phase table from an un-profiled run of the same program','cases':[]}
-for name in ('S2_x1','S4_x1','S2_x2048'):
+for name in ('S1_x1','S2_x1','S3_x1','S4_x1','S2_x2048'):
     try: plain=json.loads(open('$OUT/%s.plain.json'%name).read().strip().splitlines()[-1])
     except Exception as e: plain={'error':str(e)}
     tot=collections.OrderedDict()
@@ -51,6 +52,6 @@ for name in ('S2_x1','S4_x1','S2_x2048'):
     if c.get('TCC_HIT_sum') is not None and (c.get('TCC_HIT_sum',0)+c.get('TCC_MISS_sum',0))>0:
         e['l2_hit_rate']=c['TCC_HIT_sum']/(c['TCC_HIT_sum']+c['TCC_MISS_sum'])
     out['cases'].append(e)
-print(json.dumps(out)[:3000])
+print(json.dumps(out)[:1500])
 open('$OUT/${TAG}_pmc_k_frame.json','w').write(json.dumps(out, indent=1))
 PY
