@@ -236,6 +236,11 @@ int pam_conv3x3_layout(int H, int W, int Cin, int Cout);
  * the image for the slab returned and says so at the launch: tile_cfg -5 of pam_conv2d_nhwc_bf16_ex, which otherwise behaves like -3
  * (streamed layout stated; -4 = classic layout stated). */
 int pam_conv3x3_layout_ex(int H, int W, int Cin, int Cout, int c96_slab);
+/* Darknet's 3x3 stride-1 layers (activation codes > 1: leaky, shortcut added after the activation) on the streamed kernel: the slab
+ * width (64 for Cin 128, 32 for Cin 256 / 512) when the library has a general-activation instantiation for the shape (Cout % 64 == 0,
+ * rows that fit the patch), else 0.  The caller then packs the streamed image for slabs of that width and launches with tile_cfg -7 (any other tile_cfg keeps such layers on
+ * the classic kernel and image). */
+int pam_conv3x3_layout_gen(int H, int W, int Cin, int Cout);
 /* which kernel the calling thread's last pam_conv2d_nhwc_bf16[_ex] call launched (labels for per-kernel profiles) */
 #define PAM_CONV_KERNEL_IGEMM 0   /* k_conv_igemm */
 #define PAM_CONV_KERNEL_3X3   1   /* k_conv3x3   */

@@ -723,7 +723,7 @@ __device__ __forceinline__ void c3s_spread(std::integer_sequence<int, R...>) {
     __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
 }
 
-template <int CIN, int NTW, int MT, int PMAX, int NBUF>
+template <int CIN, int NTW, int MT, int PMAX, int NBUF, bool GEN = false>
 __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
     constexpr int BN = 16 * NTW, NCHUNK = CIN / 32;
     constexpr int PIMG = PMAX * 64, WIMG = 9 * BN * 64, BUF = PIMG + WIMG;
@@ -785,11 +785,23 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
     // ---- multiplier waves ---------------------------------------------------------------------------------------------------
     C3_STAMP(0);
     f32x4 acc[MT][NTW];
+    uint32_t gres[GEN ? MT : 1][2 * NTW];                 // GEN (Darknet activation codes): the residual rows stay in registers until the epilogue
     {
         f32x4 bias4[NTW];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) bias4[j] = a.bias ? *(const f32x4*)(a.bias + n0 + g * 4 * NTW + j * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (a.res) {
+        if (GEN && a.res) {
+            const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int p = wave * 16 * MT + i * 16 + (lane & 15);
+                const int py = fdiv_small(p, a.inv_pw), px = p - py * PW;
+                const bool ok = p < nslots && px < a.W;
+                const unsigned o = ok ? (unsigned)(((((size_t)n * a.H + ty0 + py) * a.W + px) * a.Cout + n0 + g * 4 * NTW) * 2) : OOB_OFFSET;
+                c3_row_load<NTW>(rs_res, o, g, gres[GEN ? i : 0]);
+            }
+        }
+        if (!GEN && a.res) {
             const auto rs_res = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (int)((size_t)a.N * a.H * a.W * a.Cout * 2), 0x00020000);
             uint32_t rres[MT][2 * NTW];
 #pragma unroll
@@ -882,8 +894,15 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
             uint32_t ov[2 * NTW];
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
+                if constexpr (GEN) {                     // epi_act's arithmetic: act & 3 = 0 linear / 1 ReLU / 2 leaky; act & 4: the residual is added after it
+                    const uint32_t r01 = a.res ? gres[GEN ? i : 0][2 * j] : 0u, r23 = a.res ? gres[GEN ? i : 0][2 * j + 1] : 0u;
+                    acc[i][j][0] = epi_act(acc[i][j][0], __builtin_bit_cast(float, r01 << 16), a.relu);
+                    acc[i][j][1] = epi_act(acc[i][j][1], __builtin_bit_cast(float, r01 & 0xffff0000u), a.relu);
+                    acc[i][j][2] = epi_act(acc[i][j][2], __builtin_bit_cast(float, r23 << 16), a.relu);
+                    acc[i][j][3] = epi_act(acc[i][j][3], __builtin_bit_cast(float, r23 & 0xffff0000u), a.relu);
+                }
                 ov[2 * j] = pack_bf16x2(acc[i][j][0], acc[i][j][1]); ov[2 * j + 1] = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                if (a.relu) {
+                if (!GEN && a.relu) {
                     ov[2 * j] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j]), (s16x2){0, 0}));
                     ov[2 * j + 1] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, ov[2 * j + 1]), (s16x2){0, 0}));
                 }
@@ -936,6 +955,48 @@ static bool c3s_pick(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pma
     // anything else (e.g. Cin 192 -> Cout 48) stays on k_conv3x3 / the implicit GEMM and keeps the classic weight image
     if (Cin == 256 ? ntw != 3 : ntw != 4) return false;
     return true;
+}
+// Darknet's 3x3 layers (leaky activation, shortcut added after it) on the streamed kernel: Cin 128 / 256 / 512 with 64-channel slabs, for
+// the (M tiles, patch) shapes instantiated below; anything else stays on the classic kernel.  Round 5: the detector's 29 such layers ran
+// at 12-17 % of the MFMA roof on k_conv3x3 (26 / 18.6 / 27.5 us at 52 x 52 / 26 x 26 / 13 x 13 x 5 views).
+static bool c3s_pick_gen(int H, int W, int Cin, int Cout, int& TH, int& mt, int& pmax) {
+    if ((Cin != 128 && Cin != 256 && Cin != 512) || Cout % 64 != 0) return false;
+    const int PW = W + 2;
+    TH = 0; mt = 0; pmax = 0;
+    long best = 0;
+    for (int t = (H < 320 / PW ? H : 320 / PW); t >= 1; --t) {
+        const int sl = t * PW, np = (t + 2) * PW;
+        if (sl > 320 || np > 384) continue;
+        const int m = (sl <= 256 && np <= 320) ? 4 : 5;
+        const long cost = (long)((H + t - 1) / t) * m;
+        if (TH == 0 || cost < best) { TH = t; best = cost; mt = m; pmax = m == 4 ? 320 : 384; }
+    }
+    return TH >= 1;
+}
+// slab width of the general-activation form: 64 channels for Cin = 128 (52 x 52 maps: 220 workgroups), 32 for the deeper, smaller maps
+// (26 x 26, 13 x 13: 80-120 workgroups of 64-channel slabs left most of the chip idle while each streamed 300-590 KB of weights)
+static int c3s_gen_slab(int Cin) { return Cin == 128 ? 64 : 32; }
+extern "C" int pam_conv3x3_layout_gen(int H, int W, int Cin, int Cout) {
+    int th, mt, pmax;
+    return c3s_pick_gen(H, W, Cin, Cout, th, mt, pmax) ? c3s_gen_slab(Cin) : 0;
+}
+template <int CIN, int NTW, int MT, int PMAX>
+static int launch_c3s_gen_one(hipStream_t s, const C3Args& a) {
+    constexpr size_t lds = (size_t)2 * (PMAX * 64 + 9 * 16 * NTW * 64);
+    if (!pam_max_dynamic_lds((const void*)k_conv3x3s<CIN, NTW, MT, PMAX, 2, true>, (int)lds)) return PAM_E_HIP;
+    pam_launch(k_conv3x3s<CIN, NTW, MT, PMAX, 2, true>, dim3(a.tiles_y * a.N, a.Cout / (16 * NTW)), dim3(512), lds, s, a);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+static int launch_c3s_gen(hipStream_t s, const C3Args& a, int Cin, int mt) {
+    switch (Cin * 10 + mt) {
+        case 1284: return launch_c3s_gen_one<128, 4, 4, 320>(s, a);
+        case 1285: return launch_c3s_gen_one<128, 4, 5, 384>(s, a);
+        case 2564: return launch_c3s_gen_one<256, 2, 4, 320>(s, a);
+        case 2565: return launch_c3s_gen_one<256, 2, 5, 384>(s, a);
+        case 5124: return launch_c3s_gen_one<512, 2, 4, 320>(s, a);
+        case 5125: return launch_c3s_gen_one<512, 2, 5, 384>(s, a);
+    }
+    return PAM_E_ARG;
 }
 extern "C" int pam_conv3x3_layout_ex(int H, int W, int Cin, int Cout, int c96_slab) {
     int th, mt, pmax, ntw;
@@ -1308,6 +1369,21 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     // pam_conv3x3_layout() at call time -- a launch recorded under one setting of pam_conv_option and re-issued under another must not
     // read an image in the other layout
     // -5: streamed, and a 96 -> 96 layer's image is packed for slabs of 48 output channels
+    // -7: a Darknet layer (activation code > 1 allowed) on the streamed kernel, image packed for 64-channel slabs (pam_conv3x3_layout_gen)
+    if (tile_cfg == -7) {
+        C3Args c;
+        int mt = 0, pmax = 0;
+        if (!in || !w_packed || !w_img || !out || N <= 0 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || in_cstride != Cin || relu_from != 0 ||
+            !c3s_pick_gen(H, W, Cin, Cout, c.TH, mt, pmax) || (size_t)N * H * W * Cout * 2 >= (1ull << 31)) return PAM_E_ARG;
+        c.in = (const uint16_t*)in; c.wimg = (const uint16_t*)w_img; c.bias = bias; c.res = (const uint16_t*)residual; c.out = (uint16_t*)out;
+        c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.relu = relu; c.inv_pw = 1.0f / (float)(W + 2);
+        c.tiles_y = (H + c.TH - 1) / c.TH;
+#ifdef PAM_DIAG
+        c.dbg = 0; c.stamps = nullptr;
+#endif
+        CONV_KIND(PAM_CONV_KERNEL_3X3S);
+        return launch_c3s_gen((hipStream_t)stream, c, Cin, mt);
+    }
     const int c96_slab = tile_cfg == -5 ? 48 : 0;
     const bool force_streamed = tile_cfg == -3 || c96_slab != 0, no_streamed = tile_cfg == -4;
     if (force_streamed || no_streamed) tile_cfg = -1;
@@ -1417,7 +1493,12 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
     const bool gs_ok = (relu <= 1 || leaky_gs) && KH * KW <= 9 && Cin % 8 == 0 && (size_t)N * H * W * in_cstride * 2 < (1u << 31);
     if (leaky_gs && gs_ok && tile_cfg == -1 && conv_gs_auto(a)) {
         CONV_KIND(PAM_CONV_KERNEL_GS);
-        return (Cout % 48 == 0) ? launch_conv_gs<3>((hipStream_t)stream, a) : launch_conv_gs<4>((hipStream_t)stream, a);
+        if (Cout % 48 == 0) return launch_conv_gs<3>((hipStream_t)stream, a);
+        // Darknet's widths are multiples of 64: the smallest pixel tile that still is ONE round of workgroups, as for HRNet's small fuse convolutions
+        const int nslab = Cout / 64;
+        if (((a.M + 63) / 64) * nslab <= 256) return launch_conv_gs_r<4, false, 64, 3>((hipStream_t)stream, a);
+        if (((a.M + 127) / 128) * nslab <= 256) return launch_conv_gs_r<4, false, 128, 3>((hipStream_t)stream, a);
+        return launch_conv_gs<4>((hipStream_t)stream, a);
     }
     if (tile_cfg >= 8 && tile_cfg <= 12 && !gs_ok) return PAM_E_ARG;
     if (tile_cfg == 12) {                               // 64-pixel tiles: the smallest images (12 x 9) as a few hundred short workgroups

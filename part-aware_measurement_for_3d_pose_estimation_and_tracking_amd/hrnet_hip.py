@@ -360,6 +360,7 @@ class ConvEngine(object):
             self._keep.append(y)
         return y
 
+    gen_streamed = True         # Darknet 3x3 layers with Cin 128 / 256 / 512 on k_conv3x3s<.., GEN> (False: the classic k_conv3x3)
     tile_cfg = -1
     c96_slab = 0                # 96 -> 96 3x3 layers: 0 = k_conv3x3, 48 / 96 = the streamed kernel with slabs of that many output channels
     _keep = None
@@ -391,8 +392,18 @@ class ConvEngine(object):
         # the streamed kernels (k_conv3x3s / k_conv_gs) take the activation codes 0 / 1 only: leaky / shortcut-after-activation layers
         # (the detector's) ask for the classic kernels and the classic weight image
         tile_cfg = -2 if (self.tile_cfg == -1 and act > 1) else self.tile_cfg
-        wimg = op.image(h, w, classic=(tile_cfg != -1), c96_slab=self.c96_slab) if (in_cs == cin and relu_from == 0) else None
-        if tile_cfg == -1 and wimg is not None and op._stem is None:
+        wimg = None
+        if (tile_cfg == -2 and self.gen_streamed and op.kh == 3 and op.kw == 3 and op.stride == 1 and op.pad == 1 and in_cs == cin and relu_from == 0
+                and op._w_ohwi is not None and self.lib.pam_conv3x3_layout_gen(h, w, cin, op.cout) > 0):
+            # round 5: Darknet's 3x3 layers (leaky, shortcut after the activation) on the streamed kernel's general-activation instantiations
+            bn = self.lib.pam_conv3x3_layout_gen(h, w, cin, op.cout)
+            wimg = op._images.get(('gen', bn))
+            if wimg is None:
+                wimg = op._images[('gen', bn)] = streamed_image(op._w_ohwi, bn, op._device)
+            tile_cfg = -7
+        if wimg is None:
+            wimg = op.image(h, w, classic=(tile_cfg != -1), c96_slab=self.c96_slab) if (in_cs == cin and relu_from == 0) else None
+        if tile_cfg == -1 and wimg is not None and op._stem is None and tile_cfg != -7:
             # automatic choice, but the layout of THIS image is stated: -3 streamed / -4 classic, -5 / -6 a 96 -> 96 layer streamed with
             # slabs of 48 / 96 output channels (the executor's choice, c96_slab)
             tile_cfg = ({48: -5, 96: -6}.get(getattr(op, 'last_c96', 0), -3)) if getattr(op, 'last_streamed', False) else -4
