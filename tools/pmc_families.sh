@@ -2,7 +2,7 @@
 # rocprofv3 PMC passes over ONE layer of every kernel family of the HRNet conv stack (20 crops), summarised to one JSON
 # (profiles/rNN_pmc_families.json).  Counters in their own runs (no tracing), several passes: SQ has 8 slots, TCC 4.
 # usage (GPU box, through gpurun): tools/pmc_families.sh <git commit> [round tag]
-COMMIT=${1:-unknown}; TAG=${2:-r04}
+COMMIT=${1:-unknown}; TAG=${2:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_fam; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA"
@@ -16,10 +16,13 @@ FAMS=(
  "k_conv3x3s_C96_48x36|--shape 48,36,96,96,3,1"
  "k_conv3x3s_C192_24x18|--shape 24,18,192,192,3,1"
  "k_conv3x3s_C384_12x9|--shape 12,9,384,384,3,1"
- "k_conv_gs96_3x3s2_48to192_96x72|--shape 96,72,48,192,3,2 --res 0"
- "k_conv_gs_3x3s2_96to288_48x36|--shape 48,36,96,288,3,2 --res 0"
- "k_conv_gs128_3x3s2_192to384_24x18|--shape 24,18,192,384,3,2 --res 0"
- "k_conv_gs64_3x3s2_48to48_48x36|--shape 48,36,48,48,3,2 --res 0"
+ "k_down48_3x3s2_48to192_96x72|--shape 96,72,48,192,3,2 --res 0"
+ "k_down48_3x3s2_48to144_96x72|--shape 96,72,48,144,3,2 --res 0"
+ "k_down48_3x3s2_48to192_48x36|--shape 48,36,48,192,3,2 --res 0"
+ "k_down48_3x3s2_48to384_24x18|--shape 24,18,48,384,3,2 --res 0"
+ "k_down_s_3x3s2_96to192_48x36|--shape 48,36,96,192,3,2 --res 0"
+ "k_down_s_3x3s2_96to288_48x36|--shape 48,36,96,288,3,2 --res 0"
+ "k_down_s_3x3s2_192to384_24x18|--shape 24,18,192,384,3,2 --res 0"
  "k_conv_gs_3x3s2_64to64_192x144|--shape 192,144,64,64,3,2 --res 0"
  "k_conv_gs_1x1_96to48_48x36|--shape 48,36,96,48,1,1 --res 0"
  "k_conv_gs64_1x1_384to336_12x9|--shape 12,9,384,336,1,1 --res 0"
@@ -43,7 +46,7 @@ for d in sorted(glob.glob('$OUT/*/')):
     for f in sorted(glob.glob(d+'p*/*/*counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             k=r['Kernel_Name']
-            if 'k_conv' not in k and 'k_bblock' not in k and 'k_pw' not in k and 'k_bneck' not in k and 'k_stem_fused' not in k: continue
+            if 'k_conv' not in k and 'k_bblock' not in k and 'k_pw' not in k and 'k_bneck' not in k and 'k_stem_fused' not in k and 'k_down' not in k: continue
             tot.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
     c={k:(sum(v[1:])/len(v[1:]) if len(v)>1 else v[0]) for k,v in tot.items()}
     if not c: continue

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of one HRNet forward (20 crops) from rocprofv3 PMC counters: separate passes for FETCH_SIZE and WRITE_SIZE.
 # usage (on the GPU box, through gpurun): tools/pmc_hrnet.sh <git commit of the build> [round tag]
-COMMIT=${1:-unknown}; TAG=${2:-r04}; CONFIG=${3:-fused48_fused96}       # CONFIG: the executor configuration of the 20-crop replay (HRNetPose.config_for)
+COMMIT=${1:-unknown}; TAG=${2:-r05}; CONFIG=${3:-fused48_fused96}       # CONFIG: the executor configuration of the 20-crop replay (HRNetPose.config_for)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_hrnet; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 for P in FETCH_SIZE WRITE_SIZE; do
@@ -13,14 +13,14 @@ res={}
 for P in ('FETCH_SIZE','WRITE_SIZE'):
     f=max(glob.glob('$OUT/%s/*/*counter_collection.csv'%P), key=os.path.getmtime)
     rows=[r for r in csv.DictReader(open(f)) if r['Counter_Name']==P]
-    conv=[r for r in rows if 'k_conv' in r['Kernel_Name'] or 'k_upsample' in r['Kernel_Name'] or 'k_bblock' in r['Kernel_Name'] or 'k_pw' in r['Kernel_Name'] or 'k_bneck' in r['Kernel_Name'] or 'k_stem_fused' in r['Kernel_Name']]
+    conv=[r for r in rows if 'k_conv' in r['Kernel_Name'] or 'k_upsample' in r['Kernel_Name'] or 'k_bblock' in r['Kernel_Name'] or 'k_pw' in r['Kernel_Name'] or 'k_bneck' in r['Kernel_Name'] or 'k_stem_fused' in r['Kernel_Name'] or 'k_down' in r['Kernel_Name'] or 'k_fuse_sum' in r['Kernel_Name']]
     nfw=sum(1 for r in conv if 'k_stem_fused' in r['Kernel_Name'] or 'k_conv_stem' in r['Kernel_Name'])*1.0      # one stem launch per forward
     tot=sum(float(r['Counter_Value']) for r in conv)
     res[P]={'sum_kb':tot,'forwards':nfw,'kb_per_forward':tot/nfw,'kernels_per_forward':len(conv)/nfw}
 # guide: FETCH_SIZE (KB) reads exactly half of a wide coalesced stream on gfx950 -> double it; WRITE_SIZE is exact
 res['hbm_bytes_per_forward']=(2*res['FETCH_SIZE']['kb_per_forward']+res['WRITE_SIZE']['kb_per_forward'])*1024
 res['git_commit']='$COMMIT'; res['crops']=20; res['executor_config']='$CONFIG'; res['launches_per_forward']=res['FETCH_SIZE']['kernels_per_forward']
-res['note']='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, summed over the k_stem_fused / k_bneck / k_bblock / k_conv3x3 / k_conv_gs / k_conv_igemm / k_upsample_add kernels of one 20-crop HRNet-W48 forward (tools/pmc_hrnet.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 reports half of wide coalesced reads), WRITE_SIZE taken as is'
+res['note']='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, summed over the k_stem_fused / k_bneck / k_bblock / k_conv3x3 / k_conv_gs / k_conv_igemm / k_down48 / k_down_s / k_upsample_add kernels of one 20-crop HRNet-W48 forward (tools/pmc_hrnet.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 reports half of wide coalesced reads), WRITE_SIZE taken as is'
 print(json.dumps(res))
 open('$OUT/${TAG}_hrnet_hbm_traffic.json','w').write(json.dumps(res, indent=1))
 PY
