@@ -317,6 +317,9 @@ int pam_bottleneck_fused_nhwc_bf16(void* stream, const void* y1, const void* x0,
  * 16 jt + qq = output channel 16 (qq >> 2) + 4 jt + (qq & 3), natural K order, the row's 16-byte piece at position p holds K values
  * 8 q .. 8 q + 7 with q = p ^ ((row >> 1) & 7). */
 int pam_pointwise64_relu_nhwc_bf16(void* stream, const void* in, const void* w_img, const float* bias, void* out, long long n_pixels);
+/* the same stream with the activation stated: act 1 = ReLU, 2 = leaky ReLU of slope 0.1 (Darknet's 64 -> 32 pointwise layer, its 32 filters
+ * zero-padded to 64, at 208 x 208) */
+int pam_pointwise64_act_nhwc_bf16(void* stream, const void* in, const void* w_img, const float* bias, void* out, long long n_pixels, int act);
 int pam_bottleneck_tail_nhwc_bf16(void* stream, const void* y2, const void* x0, const void* residual, const void* w3_img,
                                   const float* bias3, const void* w1_img, const float* bias1, void* out_x, void* out_y1,
                                   long long n_pixels, int tile_cfg);

@@ -78,6 +78,7 @@ _SIGS = {
     'pam_basic_block2_tile': (_I, [_I, _I, _I, _I, _P]),
     'pam_basic_block2_nhwc_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     'pam_pointwise64_relu_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, C.c_longlong]),
+    'pam_pointwise64_act_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, C.c_longlong, _I]),
     'pam_stem_fused_nhwc_bf16': (_I, [_P] * 10 + [_I, _I, _I]),
     'pam_bottleneck_fused_nhwc_bf16': (_I, [_P] * 12 + [_I, _I, _I]),
     'pam_bottleneck_tail_nhwc_bf16': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_longlong, _I]),

@@ -236,7 +236,7 @@ static int launch_pw2(hipStream_t s, const PwArgs& a, int max_wg) {
 // 128 B in, 128 B out per pixel: a pure stream.  The whole weight matrix is 8 A fragments = 32 VGPRs per lane, loaded once (w_img: chunk 0 of
 // the w1 layout below WITHOUT the K permutation, i.e. row 16 jt + qq = output channel 16 (qq >> 2) + 4 jt + (qq & 3), natural K order, pieces
 // swizzled like every chunk image); every wave streams 16-pixel tiles on its own, four tiles in flight.
-struct Pw1Args { const uint16_t* in; const uint16_t* w; const float* b; uint16_t* out; int M; };
+struct Pw1Args { const uint16_t* in; const uint16_t* w; const float* b; uint16_t* out; int M; int act; };   // act: 1 ReLU, 2 leaky ReLU (slope 0.1; Darknet)
 __global__ __launch_bounds__(256) void k_pw1(Pw1Args a) {
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, px = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,8 +276,17 @@ __global__ __launch_bounds__(256) void k_pw1(Pw1Args a) {
                 for (int j = 0; j < 4; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[h][j], __builtin_bit_cast(bf16x8_t, xb[u][h]), acc[j], 0, 0, 0);
             uint32_t o[8];
+            if (a.act == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { o[2 * j] = pw_relu2(pw_pack(acc[j][0], acc[j][1])); o[2 * j + 1] = pw_relu2(pw_pack(acc[j][2], acc[j][3])); }
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[j][r] = acc[j][r] > 0.0f ? acc[j][r] : 0.1f * acc[j][r];
+                    o[2 * j] = pw_pack(acc[j][0], acc[j][1]); o[2 * j + 1] = pw_pack(acc[j][2], acc[j][3]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o[2 * j] = pw_relu2(pw_pack(acc[j][0], acc[j][1])); o[2 * j + 1] = pw_relu2(pw_pack(acc[j][2], acc[j][3])); }
+            }
             const int m = (t0 + u) * 16 + px;
             const unsigned oo = (t0 + u < ntile && m < a.M) ? (unsigned)m * 128u + g * 32 : OOB_OFFSET;
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){o[0], o[1], o[2], o[3]}, rs_out, oo, 0, 0);
@@ -285,9 +294,13 @@ __global__ __launch_bounds__(256) void k_pw1(Pw1Args a) {
         }
     }
 }
+extern "C" int pam_pointwise64_act_nhwc_bf16(void* stream, const void* in, const void* w_img, const float* bias, void* out, long long n_pixels, int act);
 extern "C" int pam_pointwise64_relu_nhwc_bf16(void* stream, const void* in, const void* w_img, const float* bias, void* out, long long n_pixels) {
-    if (!in || !w_img || !bias || !out || n_pixels <= 0 || n_pixels * 128 >= (1ll << 31)) return PAM_E_ARG;
-    Pw1Args a; a.in = (const uint16_t*)in; a.w = (const uint16_t*)w_img; a.b = bias; a.out = (uint16_t*)out; a.M = (int)n_pixels;
+    return pam_pointwise64_act_nhwc_bf16(stream, in, w_img, bias, out, n_pixels, 1);
+}
+extern "C" int pam_pointwise64_act_nhwc_bf16(void* stream, const void* in, const void* w_img, const float* bias, void* out, long long n_pixels, int act) {
+    if (!in || !w_img || !bias || !out || n_pixels <= 0 || n_pixels * 128 >= (1ll << 31) || (act != 1 && act != 2)) return PAM_E_ARG;
+    Pw1Args a; a.in = (const uint16_t*)in; a.w = (const uint16_t*)w_img; a.b = bias; a.out = (uint16_t*)out; a.M = (int)n_pixels; a.act = act;
     const int ntile = (a.M + 15) >> 4;
     int grid = (ntile + 15) / 16;                        // 4 waves x 4 tiles per workgroup and iteration
     if (grid > 2048) grid = 2048;

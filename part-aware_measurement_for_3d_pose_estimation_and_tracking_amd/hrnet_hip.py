@@ -360,6 +360,7 @@ class ConvEngine(object):
             self._keep.append(y)
         return y
 
+    pw64 = True                 # 64 -> 64 pointwise layers over >= 64 k pixels on the streaming kernel k_pw1 (ReLU or leaky)
     gen_streamed = True         # Darknet 3x3 layers with Cin 128 / 256 / 512 on k_conv3x3s<.., GEN> (False: the classic k_conv3x3)
     tile_cfg = -1
     c96_slab = 0                # 96 -> 96 3x3 layers: 0 = k_conv3x3, 48 / 96 = the streamed kernel with slabs of that many output channels
@@ -377,6 +378,24 @@ class ConvEngine(object):
                 self.ACT[relu] <= 1 and relu_from % 16 == 0 and self.tile_cfg == -1 and
                 (x.device.type == 'meta' or self.lib.pam_conv3x3s2_slab(h, w, cin, op.cout) > 0)):
             return self.conv_down_s(op, x, relu=bool(self.ACT[relu]), relu_from=relu_from)
+        if (self.pw64 and op.kh == 1 and op.kw == 1 and op.stride == 1 and cin == 64 and op.cout == 64 and res is None and relu_from == 0 and
+                self.ACT[relu] in (1, 2) and x.device.type != 'meta' and x.is_contiguous(memory_format=torch.channels_last) and n * h * w >= 65536):
+            # a 64 -> 64 pointwise layer over many pixels (Darknet's 64 -> 32, zero-padded, at 208 x 208) is a pure stream: k_pw1
+            img = op._images.get('pw64')
+            if img is None:
+                R = torch.arange(64)
+                ch = 16 * ((R % 16) >> 2) + 4 * (R // 16) + (R & 3)
+                q = torch.arange(8)[None, :] ^ ((R >> 1) & 7)[:, None]
+                w64 = op.w[:, :64].float().cpu()[ch].reshape(64, 8, 8)
+                img = op._images['pw64'] = torch.gather(w64, 1, q[:, :, None].expand(64, 8, 8)).to(torch.bfloat16).to(op._device).contiguous()
+            y = self._new(n, 64, h, w, x.device)
+            if self.count is not None:
+                self.count['bytes'] += 2 * (x.numel() + y.numel() + 64 * 64) + 4 * 64; self.count['flops'] += 2 * y.numel() * 64; self.count['launches'] += 1
+            rc = self.lib.pam_pointwise64_act_nhwc_bf16(C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream), C.c_void_p(x.data_ptr()),
+                                                        C.c_void_p(img.data_ptr()), C.c_void_p(op.bias.data_ptr()), C.c_void_p(y.data_ptr()), n * h * w, self.ACT[relu])
+            if rc != 0:
+                raise _lib.PamError('pam_pointwise64_act_nhwc_bf16 failed (%d)' % rc)
+            return y
         in_cs = cin if x.device.type == 'meta' else x.stride(3)          # channels between neighbouring pixels
         assert cin == op.cin and (x.device.type == 'meta' or (x.stride(1) == 1 and x.stride(2) == w * in_cs and x.stride(0) == h * w * in_cs)), (x.shape, op.cin)
         ho = (h + 2 * op.pad - op.kh) // op.stride + 1

@@ -242,6 +242,7 @@ class HipDarknet(ConvEngine):
         self.device = device
         self.count = None
         self.tile_cfg = -1
+        self.unfuse_wide = True
         layers = model.layers
         n = len(layers)
         used_by = [[] for _ in range(n)]                 # consumers of each layer's output other than the next layer
@@ -306,6 +307,13 @@ class HipDarknet(ConvEngine):
             kind, dst = step[0], step[1]
             if kind == 'conv':
                 _, _, op, src, act, skip = step
+                if skip is not None and self.unfuse_wide and op.kh == 3 and op.stride == 1 and outs[src].shape[3] + 2 > 138:
+                    # rows too wide for the rows-in-LDS 3x3 kernels (the 208-wide block of the 416 x 416 network): with the shortcut
+                    # folded in, the layer fell to the classic implicit GEMM (90 us for 5 views); as a residual-free convolution it runs on
+                    # the streamed implicit GEMM and the shortcut is one k_upsample_add (round 5: 90 -> 25 + 17 us)
+                    y = self.conv(op, outs[src], relu=act)
+                    outs[dst] = self.upsample_add(y, [outs[skip]], [0], relu=False)
+                    continue
                 outs[dst] = self.conv(op, outs[src], res=outs[skip] if skip is not None else None, relu=act,
                                       res_after_act=skip is not None)
             elif kind == 'add':
