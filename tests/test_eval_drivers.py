@@ -220,3 +220,23 @@ def test_testmodel_full_pipeline_with_detector(tmp_path, capsys):
                 assert np.asarray(p).shape == (17, 3)
     saved = os.listdir(tmp_path / 'out' / 'CampusSeq1' / 'Images')
     assert any(name.endswith('_0.jpg') for name in saved)
+
+
+def test_synthetic_sequences_with_track_churn():
+    """synth.make_sequence(churn_every, churn_len): one person is invisible in every view for churn_len frames of each period (the longer
+    S3 / S4 golden traces use it to see a track death and a birth per period); without churn the sequence is what it always was."""
+    import numpy as np
+    from pam import synth
+    a = synth.make_sequence('S1', n_frames=60, seed=4)
+    b = synth.make_sequence('S1', n_frames=60, seed=4, churn_every=20, churn_len=12)
+    for t in range(60):
+        na = [len(v) for v in a['frames'][t]]
+        nb = [len(v) for v in b['frames'][t]]
+        hidden = t >= 20 and (t % 20) < 12
+        assert all(0 <= x - y <= (1 if hidden else 0) for x, y in zip(na, nb)), (t, na, nb)
+        if not hidden:
+            for va, vb in zip(a['frames'][t], b['frames'][t]):
+                assert np.array_equal(np.sort(va.reshape(len(va), -1), axis=0), np.sort(vb.reshape(len(vb), -1), axis=0))
+    assert sum(len(v) for f in b['frames'] for v in f) < sum(len(v) for f in a['frames'] for v in f)
+    c = synth.make_sequence('S1', n_frames=60, seed=4)
+    assert all(np.array_equal(x, y) for fa, fc in zip(a['frames'], c['frames']) for x, y in zip(fa, fc))
