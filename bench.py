@@ -877,15 +877,16 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
     x = torch.randn(crops, 3, 384, 288)
 
     def batch_time(thr, budget_s):
-        """seconds per batch-of-`crops` forward at `thr` threads: one warm-up forward, then up to 3 timed ones within the budget."""
+        """seconds per batch-of-`crops` forward at `thr` threads: one warm-up forward, then up to 5 timed ones within the budget; the MEDIAN
+        (round 5: the mean of 3 wandered 0.54-1.0 frames/s over four rounds)."""
         torch.set_num_threads(thr)
         t0 = time.perf_counter(); model(x); first = time.perf_counter() - t0
         if first > budget_s:
             return first, 0
-        reps, t0 = 0, time.perf_counter()
-        while reps < 1 or (reps < 3 and time.perf_counter() - t0 + first < budget_s):
-            model(x); reps += 1
-        return (time.perf_counter() - t0) / reps, reps
+        ts, t00 = [], time.perf_counter()
+        while len(ts) < 1 or (len(ts) < 5 and time.perf_counter() - t00 + first < budget_s):
+            t0 = time.perf_counter(); model(x); ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), len(ts)
     runs = []
     # All usable cores is the prescribed configuration, but on the many-core GPU hosts an oversubscribed OpenMP team is orders of magnitude
     # slower (measured: ONE crop took 201 s at 256 threads vs 0.08 s at 16; a batch-20 forward 209 s vs 1.5 s).  The all-cores batch
@@ -924,7 +925,7 @@ def cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame):
         for thr in sorted(set([usable] + [c for c in (16, 32, 64) if c < usable])) if usable < avail else ([c for c in (16, 32, 64) if c < avail] or [avail]):
             if any(r['threads'] == thr and r.get('s_per_batch') for r in runs):
                 continue
-            t_thr, reps = batch_time(thr, 6.0)
+            t_thr, reps = batch_time(thr, 10.0)
             runs.append({'threads': thr, 's_per_batch': t_thr, 'timed_forwards': reps})
             if best is None or t_thr < best[0]:
                 best = (t_thr, thr)

@@ -46,18 +46,34 @@ class FrameLoader(object):
             self.torch = torch
             self.copy_stream = torch.cuda.Stream(device)
 
-    def _slot_buffers(self, slot, shapes):
-        key = (slot, tuple(shapes))
+    def _pinned_for(self, slot, cam, shape):
+        key = (slot, cam, tuple(shape))
         with self._lock:
             buf = self._pinned.get(key)
             if buf is None:
-                buf = [self.torch.empty(s, dtype=self.torch.uint8).pin_memory() for s in shapes]
-                self._pinned[key] = buf
+                buf = self._pinned[key] = self.torch.empty(tuple(shape), dtype=self.torch.uint8).pin_memory()
         return buf
+
+    def _decode_pinned(self, path, slot, cam):
+        """Worker thread: one image file -> BGR uint8 straight into the slot's pinned staging buffer (round 5: the main thread used to
+        copy every decoded image into pinned memory itself, 12 MB per Shelf frame set, which capped the device path at ~125 frame sets/s
+        on the GPU hosts against 245 for the decode alone)."""
+        from PIL import Image
+        with Image.open(path) as im:
+            rgb = np.asarray(im.convert('RGB'))
+        pin = self._pinned_for(slot, cam, rgb.shape)
+        np.copyto(pin.numpy(), rgb[:, :, ::-1])
+        return pin
 
     def _submit(self, k):
         files = self.frames[self.indices[k]]
-        return [self.pool.submit(decode_bgr, f) for f in files]
+        if self.device is None:
+            return [self.pool.submit(decode_bgr, f) for f in files]
+        slot = k % (self.depth + 1)
+        prev = self._slot_events.get(slot)
+        if prev is not None:
+            prev.synchronize()                           # the async copy out of this pinned slot (depth + 1 frames ago) has finished: safe to overwrite
+        return [self.pool.submit(self._decode_pinned, f, slot, c) for c, f in enumerate(files)]
 
     def __iter__(self):
         pending = deque()
@@ -68,23 +84,18 @@ class FrameLoader(object):
         while pending:
             k, futs = pending.popleft()
             imgs = [f.result() for f in futs]
-            if nxt < n:
-                pending.append((nxt, self._submit(nxt))); nxt += 1
             ts = timestamp_of(self.name, self.frames[self.indices[k]][0])
             if self.device is None:
+                if nxt < n:
+                    pending.append((nxt, self._submit(nxt))); nxt += 1
                 yield self.indices[k], imgs, ts
                 continue
             torch = self.torch
             slot = k % (self.depth + 1)
-            stage = self._slot_buffers(slot, [im.shape for im in imgs])
-            prev = self._slot_events.get(slot)
-            if prev is not None:
-                prev.synchronize()                       # the earlier async copy out of this pinned slot has finished: safe to overwrite
             out = []
             consumer = torch.cuda.current_stream(self.device)
             with torch.cuda.stream(self.copy_stream):
-                for im, pin in zip(imgs, stage):
-                    pin.numpy()[...] = im
+                for pin in imgs:
                     t = pin.to(self.device, non_blocking=True)
                     # the block belongs to copy_stream's pool; the consumer reads it on ITS stream after only a wait_event, so tell
                     # the caching allocator -- otherwise the block can be handed to the next frame's copy while kernels still read it
@@ -93,6 +104,8 @@ class FrameLoader(object):
                 ev = torch.cuda.Event(); ev.record(self.copy_stream)
             self._slot_events[slot] = ev
             consumer.wait_event(ev)
+            if nxt < n:                                  # frame k + depth takes the slot of frame k - 1, whose copy was issued a step ago
+                pending.append((nxt, self._submit(nxt))); nxt += 1
             yield self.indices[k], out, ts
 
     def close(self):

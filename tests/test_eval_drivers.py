@@ -111,6 +111,36 @@ def test_frame_loader_matches_loadimages(tmp_path):
 
 
 @pytest.mark.gpu
+def test_frame_loader_device_path_matches_the_host_path(tmp_path):
+    """The workers decode straight into pinned staging buffers that are reused every depth + 1 frames; the uploaded tensors equal the host
+    decode for every frame of a run longer than the ring, incl. cameras of different sizes."""
+    import torch
+    from PIL import Image
+    from pam.ingest import FrameLoader
+    rng = np.random.default_rng(1)
+    sizes = {'Camera0': (24, 32), 'Camera1': (24, 32), 'Camera2': (30, 20)}
+    for cam, (h, w) in sizes.items():
+        os.makedirs(tmp_path / cam)
+        for i in range(23):
+            Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).save(tmp_path / cam / ('%03d.jpg' % i), quality=90)
+    ds = pam.dataset.AttrDict(dict(ROOT=str(tmp_path), FOLDERS_ORDER=list(sizes), DATA_FORMAT='*.jpg'))
+    files = LoadFilenames(ds)
+    dev = torch.device('cuda:0')
+    loader = FrameLoader('Shelf', files, workers=4, depth=3, device=dev)
+    kept, seen = [], []
+    for idx, imgs, ts in loader:
+        kept.append(imgs)                             # hold on to every frame: later uploads must not overwrite earlier tensors
+        seen.append(idx)
+    loader.close()
+    torch.cuda.synchronize()
+    assert seen == list(range(23))
+    for idx, imgs in zip(seen, kept):
+        ref, _ = LoadImages('Shelf', files[idx])
+        for a, b in zip(imgs, ref):
+            assert a.is_cuda and a.dtype == torch.uint8 and np.array_equal(a.cpu().numpy(), b)
+
+
+@pytest.mark.gpu
 def test_evalmodel_loop_on_synthetic_dataset(tmp_path, capsys):
     """evalmodel.py's loop end to end: images on disk, calibration pickle, precomputed 2D poses -> result pickle identical to
     the oracle's output, PCP table printed."""
