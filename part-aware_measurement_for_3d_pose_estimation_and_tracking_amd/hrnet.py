@@ -466,10 +466,13 @@ class HRNetPose(object):
         """Executor configuration of the n-crop forward (HipHRNet.CONFIGS).  With ``autotune`` a fixed rule from interleaved A/B runs over
         crop counts (tools/ab_flags.py fused:block2=3 res48:block2=1, end of round 4): from 8 to 12 crops the 96-channel branch runs as
         streamed convolutions (-0.4 ... -1.3 %: a 64- to 96-item fused launch is a longer chain than it is worth on a half-empty chip);
-        below (2-6 crops: +1.3 ... +3.3 % for that form) and above (16: +3.0 %) both fine branches are fused.  (Round 3 timed every
+        below (2-6 crops: +1.3 ... +3.3 % for that form) and above (16: +3.0 %) both fine branches are fused; round 5: up to 6 crops the
+        fuse-layer sums also carry their 1x1 products (k_fuse_sum: -1.7 ... -1.9 % there, a loss from 12 crops on).  (Round 3 timed every
         configuration at the first replay of a crop count: 1.5 s per count, a choice decided by noise -- the configurations were 0.4-3 %
         apart -- and three dead captures per count that could never be destroyed, see _lib.new_graph.)"""
-        name = 'resident48_streamed96' if (self.autotune and 8 <= n <= 12) else type(self.hip).config_name
+        name = type(self.hip).config_name
+        if self.autotune:
+            name = 'fused48_fused96_fsum' if n <= 6 else ('resident48_streamed96' if 8 <= n <= 12 else name)
         self.tuned[n] = {'choice': name}
         return name
 

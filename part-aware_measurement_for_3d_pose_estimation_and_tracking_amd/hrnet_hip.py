@@ -825,8 +825,11 @@ class HipHRNet(ConvEngine):
     # fused48_fused96 -8.2 %; 20 crops -3.3 / -7.3 %; 40 crops -4.1 / -8.9 %; 60 crops -5.7 / -11.2 %; 112 crops -1.7 / -7.6 %; 217 crops
     # +0.3 / -6.9 %.
     CONFIGS = {
-        'fused48_fused96': dict(block2=3, c96_slab=48),              # both fine branches: ONE fused-BasicBlock launch per block (csrc/pam_block2.hip)
-        'resident48_streamed96': dict(block2=1, c96_slab=48),        # 48-channel branch fused, 96-channel branch as two streamed convolutions per block
+        'fused48_fused96': dict(block2=3, c96_slab=48, fused_sums=False),          # both fine branches: ONE fused-BasicBlock launch per block (csrc/pam_block2.hip)
+        'resident48_streamed96': dict(block2=1, c96_slab=48, fused_sums=False),    # 48-channel branch fused, 96-channel branch as two streamed convolutions per block
+        # round 5: up to 6 crops the fuse layers' 1x1 products run inside the sum launches (k_fuse_sum: 203 launches): a forward that small
+        # is a chain of launch latencies (interleaved A/B: 2 crops -1.7 %, 4 -1.9 %, 6 -1.9 %, 8 -0.2 %, 12 +0.9 %, 20 +0.3 ... +1.5 %)
+        'fused48_fused96_fsum': dict(block2=3, c96_slab=48, fused_sums=True),
     }
 
     def apply_config(self, name):

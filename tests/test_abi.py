@@ -145,6 +145,8 @@ def test_algorithmic_work_is_executor_independent_and_launch_counts_follow_the_c
     assert a['bytes'] == b['bytes'] and a['flops'] == b['flops']
     assert abs(a['flops'] / (20 * hrnet.count_flops()) - 1) < 5e-3   # the stem's padded input channels (8 for 3) are the difference
     assert a["launches"] == 221 and b["launches"] == 253 and a['bytes_as_executed'] < b['bytes_as_executed']
+    c = w['fused48_fused96_fsum']                                    # the small-forward configuration: the 1x1 products inside the sum launches
+    assert c['launches'] == 203 and c['bytes'] == a['bytes'] and c['flops'] == a['flops'] and c['bytes_as_executed'] < a['bytes_as_executed']
     assert a['bytes'] < a['bytes_as_executed']                       # the deep branches' block interiors are traffic only as executed
     assert hrnet.algorithmic_work(40)['bytes'] > 1.9 * a['bytes']    # activations scale with the crops, the weights do not
 

@@ -555,7 +555,7 @@ def test_configuration_follows_the_crop_count_and_stays_consistent():
     y3 = b.features(x, slot=1).clone()
     torch.cuda.synchronize()
     assert b.tuned[9]['choice'] == 'resident48_streamed96' and a.tuned[9]['choice'] == hrnet_hip.HipHRNet.config_name == 'fused48_fused96'
-    assert b.config_for(4) == 'fused48_fused96' and b.config_for(16) == 'fused48_fused96'
+    assert b.config_for(4) == 'fused48_fused96_fsum' and b.config_for(16) == 'fused48_fused96'          # up to 6 crops: fused sums (round 5)
     assert torch.equal(y1, y2) and torch.equal(y1, y3)
     assert float((y1.float() - ref).norm() / ref.norm()) < 1e-2
     x20 = b.input_buffer(20)
