@@ -364,6 +364,14 @@ int pam_fuse_sum_nhwc_bf16(void* stream, const void* base, int n_plain, const vo
                            const float* const* up_bias, void* out, int N, int H, int W, int C, int relu, int tile_a, int tile_b,
                            int max_workgroups);
 
+/* ---- round 5: device-side ordering of the forward's branch streams (csrc/pam_sync.hip; the module-end exchange of hrnet.py:64-100 inside
+ * the absent HRNet backend, /root/reference/src/ivclabpose.py:210).  pam_flag_signal: one agent-scope atomic add on *dev_counter behind
+ * everything already queued on `stream`.  pam_flag_gate: [arrive != 0: first the same add, then] `stream` goes on once *dev_counter >= target (one wave polls; the launches that
+ * follow on the stream see what the signalling streams' earlier kernels wrote); after max_us microseconds it sets *dev_err = 1 and lets
+ * the stream go on regardless -- the caller checks dev_err.  Counters are zeroed by the caller in front of the first signal. */
+int pam_flag_signal(void* stream, int32_t* dev_counter);
+int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, int max_us, int arrive);
+
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before
  * the cross-view match every rank contributes its views' keypoint records and receives everyone's: ONE all-gather per frame, enqueued on

@@ -319,6 +319,7 @@ class HRNetPose(object):
         # every golden of this repository was made with); True = upstream simple-HRNet's PIL / torchvision Resize, which filters with a triangle
         # that widens with the down-scaling factor (HD Panoptic boxes taller than 384 pixels) -- csrc/pam_image.hip
         self.antialias = bool(antialias)
+        self.flag_synced = {}        # (crops, kind, slot) -> the replay orders its branch streams by device-side flags (False: stream events)
         self.captures = 0            # hipGraph captures made so far (a capture inside a frame is a stall of hundreds of ms: warm())
         # predict() pads a batch to the next multiple of graph_bucket crops (repeating its last box; the padded rows are not
         # decoded): a sequence whose person count wanders then replays a handful of captured graphs instead of capturing one
@@ -393,18 +394,43 @@ class HRNetPose(object):
                     for _ in range(2):
                         self._forward(static_in, kind)
                 torch.cuda.current_stream(self.device).wait_stream(s)
-                graph = _lib.new_graph()
-                with torch.cuda.graph(graph, pool=self._pool_of(slot)):
-                    static_out = self._forward(static_in, kind)
-                self.captures += 1
+                graph, static_out, flags = self._capture(static_in, kind, slot, self._flag_sync_ok())
+                if flags is not None:
+                    # the flagged replay once, then its error word: a gate that timed out (two branch chains on one in-order hardware queue,
+                    # a profiler that serialises kernels) -> this process goes back to stream events, for this and every later capture
+                    # (the flagged capture stays alive: captured graphs are never destroyed, _lib.new_graph)
+                    graph.replay()
+                    torch.cuda.synchronize(self.device)
+                    if int(flags[0].item()) != 0:
+                        self._flag_sync_failed = True
+                        self._flagged_dead = getattr(self, '_flagged_dead', []) + [(graph, static_out, flags)]
+                        graph, static_out, flags = self._capture(static_in, kind, slot, False)
             self.hip.arena = None
             g = (graph, static_in, static_out)
             self._graphs[(n, kind, slot)] = g
+            self.flag_synced[(n, kind, slot)] = flags is not None
         graph, static_in, static_out = g
         if static_in.data_ptr() != x.data_ptr():
             static_in.copy_(x)
         graph.replay()
         return static_out
+
+    def _flag_sync_ok(self):
+        return bool(self.hip.flag_sync) and not getattr(self, '_flag_sync_failed', False) and os.environ.get('PAM_FLAG_SYNC', '1') != '0'
+
+    def _capture(self, static_in, kind, slot, flags_on):
+        """Capture one forward on static_in; flags_on: the branch streams are ordered by device-side flags (hrnet_hip.HipHRNet)."""
+        self.hip.flags_on = bool(flags_on)
+        try:
+            graph = _lib.new_graph()
+            with torch.cuda.graph(graph, pool=self._pool_of(slot)):
+                static_out = self._forward(static_in, kind)
+            flags = self.hip._flags if flags_on else None
+        finally:
+            self.hip.flags_on = False
+            self.hip._flags = None
+        self.captures += 1
+        return graph, static_out, flags
 
     def _arena_for(self, n, slot):
         """The activation arena the n-crop capture of `slot` allocates from (created / replaced by a larger one on demand)."""

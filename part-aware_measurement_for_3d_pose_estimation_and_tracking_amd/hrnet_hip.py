@@ -857,6 +857,42 @@ class HipHRNet(ConvEngine):
         if self.stamp is not None:
             self.stamp(tag)
 
+    # -- device-side ordering of the branch streams (round 5, csrc/pam_sync.hip) ----------------------------------------------------------
+    # A module ends with a full exchange (every sum reads every branch).  As stream events in a captured hipGraph that join costs 15-21 us
+    # of idle chip per module (two cross-queue hops through the caller's stream); with flags the branch streams are independent chains that
+    # meet through a counter in device memory: a branch's chain ends with a signal launch, a one-wave gate launch in front of every sum polls
+    # the module's counter.  HRNetPose switches this on around a capture (flags_on) and checks the error word after the first replay: a
+    # gate that timed out (two chains mapped onto one in-order hardware queue, a profiler serialising kernels) means a re-capture with stream events.
+    flag_sync = True            # policy: captured replays use flags (HRNetPose._run); False / PAM_FLAG_SYNC=0: stream events everywhere
+    flags_on = False            # state: this forward is being issued with flags
+    flag_max_us = 2000000       # a gate gives up after 2 s (a systematic deadlock, found by the check after the first replay) and raises the error word
+    _flags = None
+
+    def _flag_begin(self):
+        """counters + error word of ONE forward (word 0 = error); zeroed on the caller's stream in front of the fork -- inside a capture the
+        fill is a node of the graph, i.e. it runs at every replay"""
+        self._flags = torch.zeros(64, dtype=torch.int32, device=self.device)
+        self._flag_next = 1
+        if self._keep is not None:
+            self._keep.append(self._flags)
+
+    def _flag_new(self):
+        i = self._flag_next
+        self._flag_next += 1
+        assert i < 64
+        return i
+
+    def _sig(self, i):
+        rc = self.lib.pam_flag_signal(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.c_void_p(self._flags.data_ptr() + 4 * i))
+        if rc != 0:
+            raise _lib.PamError('pam_flag_signal failed (%d)' % rc)
+
+    def _gate(self, i, target, arrive=False):
+        rc = self.lib.pam_flag_gate(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.c_void_p(self._flags.data_ptr() + 4 * i),
+                                    int(target), C.c_void_p(self._flags.data_ptr()), int(self.flag_max_us), 1 if arrive else 0)
+        if rc != 0:
+            raise _lib.PamError('pam_flag_gate failed (%d)' % rc)
+
     def _branch_blocks(self, mod, b, blocks, x):
         """The BasicBlocks of branch b on the current stream."""
         fused = mod['fused'][b]
@@ -881,10 +917,14 @@ class HipHRNet(ConvEngine):
         xs = list(xs)
         fuse = mod['fuse']
         terms = [dict() for _ in fuse]
+        flags = self.flags_on and self.multi_stream
+        ctail = self._flag_new() if flags else None
         for b in [q for q in self.order if q < len(mod['branches'])]:
             with torch.cuda.stream(self._stream(b)):
                 x = xs[b]
                 if isinstance(x, tuple):                              # transition conv runs on the new branch's own stream
+                    if flags and len(x) > 3 and x[3] is not None:
+                        self._gate(x[3], 1)                           # ... behind the sum it reads, which another stream issued
                     x = self.conv(x[1], x[2], relu=True)
                 self._st('b%d start' % b)
                 x = self._branch_blocks(mod, b, mod['branches'][b], x)
@@ -916,12 +956,17 @@ class HipHRNet(ConvEngine):
                             t = self.conv(op, t, relu=(k0 + k < len(f[1]) - 1))
                         terms[i][b] = (t, 0)
                 self._st('b%d tail' % b)
-        self._barrier()
+                if flags and b >= len(fuse):
+                    self._sig(ctail)                                  # a branch without an output of its own only arrives (the last module of stage 4)
+        if not flags:
+            self._barrier()
         self._st('join')
         # out_i = relu(x_i + sum_{j>i} up(conv1x1(x_j)) + sum_{j<i} strided-conv-chain(x_j)), terms in branch order
         out = [None] * len(fuse)
         for i in [q for q in self.order if q < len(fuse)]:
             with torch.cuda.stream(self._stream(i)):
+                if flags:
+                    self._gate(ctail, len(mod['branches']), arrive=True)   # this stream's chain is done; wait for every other branch's
                 tl = [terms[i][j] for j in sorted(terms[i])]
                 fs = mod['fsum'][i] if self.fused_sums else None
                 if fs is not None:                                    # plain (down-chain) terms + the coarser branches through their 1x1 products
@@ -955,6 +1000,8 @@ class HipHRNet(ConvEngine):
             self.arena.epoch()
 
     def _features(self, x8):
+        if self.flags_on and self.multi_stream and x8.device.type != 'meta':
+            self._flag_begin()
         x = self._head(x8)
         if self.stop_after in ('stem', 'layer1'):
             return x
@@ -997,6 +1044,16 @@ class HipHRNet(ConvEngine):
                 x = self.conv(b['c3'], y, res=r, relu=True)
         return x
 
+    def _new_branch(self, op, xs):
+        """The lazy transition of a stage's new branch: it reads the last output of the previous stage, which stream len(xs) - 1 issued."""
+        if self.flags_on and self.multi_stream:
+            f = self._flag_new()
+            with torch.cuda.stream(self._stream(len(xs) - 1)):
+                self._sig(f)                                          # behind that stream's sum
+            return ('lazy', op, xs[-1], f)
+        self._barrier()
+        return ('lazy', op, xs[-1])
+
     def _body(self, x):
         """stages 2-4 on the branch streams"""
         self._barrier()                                               # fork: branch streams must see layer1's output
@@ -1005,14 +1062,12 @@ class HipHRNet(ConvEngine):
             xs = self._hr_module(m, xs)
         if self.stop_after == 'stage2':
             return self._end(xs)
-        self._barrier()                                               # the new branch's stream reads the last sum of stage 2
-        xs = xs + [('lazy', self.t2, xs[-1])]
+        xs = xs + [self._new_branch(self.t2, xs)]                     # the new branch's stream reads the last sum of stage 2
         for m in self.stage3:
             xs = self._hr_module(m, xs)
         if self.stop_after == 'stage3':
             return self._end(xs)
-        self._barrier()
-        xs = xs + [('lazy', self.t3, xs[-1])]
+        xs = xs + [self._new_branch(self.t3, xs)]
         for m in self.stage4:
             xs = self._hr_module(m, xs)
         return self._end(xs)

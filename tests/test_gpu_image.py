@@ -610,3 +610,25 @@ def test_preprocess_antialias_matches_the_pil_formula(net):
         # the cut-out crop -- does not); a down-scaled box of random pixels is visibly smoother
         assert (d > 0.2) if down else (d <= 2.0 ** -7 * 2.7 + 1e-3), (i, down, d)
     assert float(x[:, 3:].float().abs().max()) == 0.0
+
+
+def test_replays_order_their_branch_streams_by_device_flags_and_fall_back_when_a_gate_times_out():
+    """Captured forwards meet at the module ends through counters in device memory (csrc/pam_sync.hip) instead of stream events: same
+    features as the eager forward (which uses stream events), error word zero over many replays; a capture whose first replay raises the
+    error word (here: a time-out of 1 us, which every gate exceeds) is replaced by one with stream events, with the same result."""
+    from pam import hrnet
+    a = hrnet.HRNetPose(48, 17, None, use_graph=False)
+    b = hrnet.HRNetPose(48, 17, None, use_graph=True)
+    x = a.input_buffer(5)
+    x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(x.device).to(x.dtype)); x[:, 3:] = 0
+    ref = a.features(x).clone()
+    for _ in range(10):
+        y = b.features(x)
+    torch.cuda.synchronize()
+    assert b.flag_synced[(5, 'features', 0)] is True and torch.equal(ref, y)
+    c = hrnet.HRNetPose(48, 17, None, use_graph=True)
+    c.hip.flag_max_us = 1
+    y2 = c.features(x).clone()
+    torch.cuda.synchronize()
+    assert c.flag_synced[(5, 'features', 0)] is False and c.captures == 2 and torch.equal(ref, y2)
+    assert c._flag_sync_ok() is False                   # and the process stays with stream events
