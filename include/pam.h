@@ -368,9 +368,11 @@ int pam_fuse_sum_nhwc_bf16(void* stream, const void* base, int n_plain, const vo
  * the absent HRNet backend, /root/reference/src/ivclabpose.py:210).  pam_flag_signal: one agent-scope atomic add on *dev_counter behind
  * everything already queued on `stream`.  pam_flag_gate: [arrive != 0: first the same add, then] `stream` goes on once *dev_counter >= target (one wave polls; the launches that
  * follow on the stream see what the signalling streams' earlier kernels wrote); after max_us microseconds it sets *dev_err = 1 and lets
- * the stream go on regardless -- the caller checks dev_err.  Counters are zeroed by the caller in front of the first signal. */
+ * the stream go on regardless -- the caller checks dev_err (and host_err, when given: a word of pinned host memory that receives 1 at a
+ * time-out, readable by the host without touching the device; NULL = none).  Counters are zeroed by the caller in front of the first
+ * signal.  Flagged forwards of one process must not be in flight at the same time (their gates can block each other's queues). */
 int pam_flag_signal(void* stream, int32_t* dev_counter);
-int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, int max_us, int arrive);
+int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, int max_us, int arrive, int32_t* host_err);
 
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before

@@ -88,7 +88,7 @@ _SIGS = {
     'pam_conv3x3s2_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P] + [_I] * 7),
     'pam_fuse_sum_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 8),
     'pam_flag_signal': (_I, [_P, _P]),
-    'pam_flag_gate': (_I, [_P, _P, _I, _P, _I, _I]),
+    'pam_flag_gate': (_I, [_P, _P, _I, _P, _I, _I, _P]),
     'pam_comm_unique_id': (_I, [_P]),
     'pam_comm_init': (_I, [C.POINTER(_P), _I, _I, _P, _I]),
     'pam_comm_destroy': (_I, [_P]),

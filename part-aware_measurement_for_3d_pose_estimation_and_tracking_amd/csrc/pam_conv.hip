@@ -847,6 +847,9 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
         const char* buf = smem + (size_t)((unsigned)k % (unsigned)NBUF) * BUF;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) bf_[j] = *(const bf16x8*)(buf + woff + (t * BN + j * 16) * 64);
+#ifdef PAM_KO_PIXREADS                                     // timing knock-out (wrong results): pixel fragments read for the kx = 0 taps only
+        if (t % 3 == 0)
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i) af_[i] = *(const bf16x8*)(buf + aoff0[t] + i * 1024);
     };

@@ -85,10 +85,15 @@ extern "C" int pam_upsample_concat_nhwc_bf16(void* stream, const void* a, const 
 
 // ---- YOLO head decode + greedy NMS for one class --------------------------------------------------------------------
 // One workgroup per image.  Candidates are numbered head-major, then cell (row-major), then anchor.  Pass 1 keeps, in
-// that order, every candidate with sigmoid(objectness) * sigmoid(class logit) > score_thresh (ordered ballot/prefix
-// compaction into LDS, at most PAM_YOLO_MAX_CAND); pass 2 is the classic greedy NMS: repeatedly take the best surviving
-// score (ties: lowest candidate number), emit it, and drop every survivor whose IoU with it exceeds nms_thresh.
+// that order, every candidate with sigmoid(objectness) * sigmoid(class logit) > score_thresh (at most PAM_YOLO_MAX_CAND of them enter
+// NMS): a thread takes DET_K consecutive candidates per round and has all their score loads in flight at once (round 5: one candidate
+// per thread and three barriers per 1 024 candidates was 11 serial memory round trips = 35 us of the 87 us launch), the kept ones are
+// compacted in order through a block scan of the per-thread counts.  Pass 2 is the classic greedy NMS -- repeatedly take the best
+// surviving score (ties: lowest candidate number), emit it, drop every survivor whose IoU with it exceeds nms_thresh -- run by ONE wave
+// with the candidates in registers (NJ per lane), so a round is a wave reduction and NJ IoU tests without a workgroup barrier (two
+// barriers per emitted box before: 1.5 us x 36 boxes of a random-weight network).
 #define DET_T 1024
+#define DET_K 8
 struct YoloArgs {
     const uint16_t* head[3];
     int gh[3], gw[3], cs[3];
@@ -103,81 +108,128 @@ struct DBest { float v; int i; };
 __device__ __forceinline__ DBest dbetter(DBest a, DBest b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ __launch_bounds__(DET_T) void k_yolo_detect(YoloArgs a) {
-    __shared__ float cx1[PAM_YOLO_MAX_CAND], cy1[PAM_YOLO_MAX_CAND], cx2[PAM_YOLO_MAX_CAND], cy2[PAM_YOLO_MAX_CAND], csc[PAM_YOLO_MAX_CAND];
-    __shared__ int wtot[DET_T / 64];
-    __shared__ DBest red[DET_T / 64];
-    __shared__ int s_running;
-    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per[3] = {a.gh[0] * a.gw[0] * 3, a.gh[1] * a.gw[1] * 3, a.gh[2] * a.gw[2] * 3};
-    const int total = per[0] + per[1] + per[2];
-    const int stride_a = 5 + a.nc;
-    if (tid == 0) s_running = 0;
-    __syncthreads();
-    for (int base = 0; base < total; base += DET_T) {
-        const int q = base + tid;
-        bool keep = false;
-        float bx1 = 0, by1 = 0, bx2 = 0, by2 = 0, sc = 0;
-        if (q < total) {
-            int h = 0, r = q;
-            if (r >= per[0]) { r -= per[0]; h = 1; if (r >= per[1]) { r -= per[1]; h = 2; } }
-            const int cell = r / 3, an = r - cell * 3;
-            const int gy = cell / a.gw[h], gx = cell - gy * a.gw[h];
-            const uint16_t* p = a.head[h] + (((size_t)img * a.gh[h] + gy) * a.gw[h] + gx) * a.cs[h] + an * stride_a;
-            sc = sigmoidf_(bf16_to_f32(p[4])) * sigmoidf_(bf16_to_f32(p[5 + a.cls]));
-            if (sc > a.score_thresh) {
-                keep = true;
-                const float bx = (sigmoidf_(bf16_to_f32(p[0])) + (float)gx) / (float)a.gw[h];
-                const float by = (sigmoidf_(bf16_to_f32(p[1])) + (float)gy) / (float)a.gh[h];
-                const float bw = expf(bf16_to_f32(p[2])) * a.anchors[(h * 3 + an) * 2 + 0] / (float)a.net_w;
-                const float bh = expf(bf16_to_f32(p[3])) * a.anchors[(h * 3 + an) * 2 + 1] / (float)a.net_h;
-                bx1 = (bx - 0.5f * bw) * (float)a.frame_w; bx2 = (bx + 0.5f * bw) * (float)a.frame_w;
-                by1 = (by - 0.5f * bh) * (float)a.frame_h; by2 = (by + 0.5f * bh) * (float)a.frame_h;
-            }
-        }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wtot[wave] = __popcll(m);
-        __syncthreads();
-        int off = s_running;
-        for (int w = 0; w < wave; ++w) off += wtot[w];
-        off += __popcll(m & ((1ull << lane) - 1ull));
-        if (keep && off < PAM_YOLO_MAX_CAND) { cx1[off] = bx1; cy1[off] = by1; cx2[off] = bx2; cy2[off] = by2; csc[off] = sc; }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < DET_T / 64; ++w) t += wtot[w]; s_running += t; }
-        __syncthreads();
+struct DetLds {
+    float x1[PAM_YOLO_MAX_CAND], y1[PAM_YOLO_MAX_CAND], x2[PAM_YOLO_MAX_CAND], y2[PAM_YOLO_MAX_CAND], sc[PAM_YOLO_MAX_CAND];
+    int wtot[DET_T / 64];
+    int running;
+};
+
+// greedy NMS of candidates 0 .. ncand - 1 (ncand <= 64 NJ) by one wave: candidate j * 64 + lane lives in slot j of lane `lane`
+template <int NJ, bool REGS>                                 // REGS: the boxes live in registers too (NJ <= 4); else they are re-read from LDS every round
+__device__ __forceinline__ int det_nms_wave(const YoloArgs& a, const DetLds& L, int img, int ncand, int lane) {
+    float mx1[REGS ? NJ : 1], my1[REGS ? NJ : 1], mx2[REGS ? NJ : 1], my2[REGS ? NJ : 1], msc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int c = j * 64 + lane;
+        const bool ok = c < ncand;
+        if (REGS) { mx1[j] = ok ? L.x1[c] : 0.f; my1[j] = ok ? L.y1[c] : 0.f; mx2[j] = ok ? L.x2[c] : 0.f; my2[j] = ok ? L.y2[c] : 0.f; }
+        msc[j] = ok ? L.sc[c] : -1.0f;                                  // a dead or absent candidate has score -1
     }
-    const int nfound = s_running;
-    const int ncand = nfound < PAM_YOLO_MAX_CAND ? nfound : PAM_YOLO_MAX_CAND;
-    // greedy NMS; one candidate per thread (PAM_YOLO_MAX_CAND == DET_T)
-    bool alive = tid < ncand;
-    const float mx1 = alive ? cx1[tid] : 0, my1 = alive ? cy1[tid] : 0, mx2 = alive ? cx2[tid] : 0, my2 = alive ? cy2[tid] : 0;
-    const float marea = (mx2 - mx1) * (my2 - my1);
     int kept = 0;
     while (kept < a.max_det) {
-        DBest b; b.v = alive ? csc[tid] : -1.0f; b.i = tid;
+        DBest b; b.v = msc[0]; b.i = lane;
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) { DBest t; t.v = msc[j]; t.i = j * 64 + lane; b = dbetter(b, t); }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { DBest t; t.v = __shfl_xor(b.v, o, 64); t.i = __shfl_xor(b.i, o, 64); b = dbetter(b, t); }
-        if (lane == 0) red[wave] = b;
-        __syncthreads();
-        b = red[0];
-#pragma unroll
-        for (int w = 1; w < DET_T / 64; ++w) b = dbetter(b, red[w]);
-        if (b.v < 0.0f) break;                                   // uniform: every thread reads the same red[]
-        const float kx1 = cx1[b.i], ky1 = cy1[b.i], kx2 = cx2[b.i], ky2 = cy2[b.i];
-        if (tid == 0) {
+        if (b.v < 0.0f) break;                                          // uniform
+        const float kx1 = L.x1[b.i], ky1 = L.y1[b.i], kx2 = L.x2[b.i], ky2 = L.y2[b.i];
+        if (lane == 0) {
             float* row = a.out + ((size_t)img * a.max_det + kept) * 5;
             row[0] = kx1; row[1] = ky1; row[2] = kx2; row[3] = ky2; row[4] = b.v;
         }
-        if (alive) {
-            const float iw = fminf(mx2, kx2) - fmaxf(mx1, kx1), ih = fminf(my2, ky2) - fmaxf(my1, ky1);
+        const float karea = (kx2 - kx1) * (ky2 - ky1);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int c = min(j * 64 + lane, PAM_YOLO_MAX_CAND - 1);
+            const float x1 = REGS ? mx1[REGS ? j : 0] : L.x1[c], y1 = REGS ? my1[REGS ? j : 0] : L.y1[c];
+            const float x2 = REGS ? mx2[REGS ? j : 0] : L.x2[c], y2 = REGS ? my2[REGS ? j : 0] : L.y2[c];
+            const float iw = fminf(x2, kx2) - fmaxf(x1, kx1), ih = fminf(y2, ky2) - fmaxf(y1, ky1);
             const float inter = (iw > 0.0f && ih > 0.0f) ? iw * ih : 0.0f;
-            const float uni = marea + (kx2 - kx1) * (ky2 - ky1) - inter;
-            if (tid == b.i || inter > a.nms_thresh * uni) alive = false;
+            const float uni = (x2 - x1) * (y2 - y1) + karea - inter;
+            if (msc[j] >= 0.0f && (j * 64 + lane == b.i || inter > a.nms_thresh * uni)) msc[j] = -1.0f;
         }
         ++kept;
-        __syncthreads();                                         // red[] is rewritten next round
     }
-    if (tid == 0) { a.count[img] = kept; a.count[a.n_img + img] = nfound; }
+    return kept;
+}
+
+__global__ __launch_bounds__(DET_T) void k_yolo_detect(YoloArgs a) {
+    __shared__ DetLds L;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per0 = a.gh[0] * a.gw[0] * 3, per1 = a.gh[1] * a.gw[1] * 3, per2 = a.gh[2] * a.gw[2] * 3;
+    const int total = per0 + per1 + per2;
+    const int stride_a = 5 + a.nc;
+    if (tid == 0) L.running = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += DET_T * DET_K) {
+        // candidate q -> address of its 5 + nc values; the loads of all DET_K candidates are issued before the first is used
+        const uint16_t* ptr[DET_K];
+        uint16_t vo[DET_K], vc[DET_K];
+#pragma unroll
+        for (int k = 0; k < DET_K; ++k) {
+            const int q = min(base + tid * DET_K + k, total - 1);      // clamped: a candidate past the end is loaded (again) and dropped
+            int h = 0, r = q;
+            if (r >= per0) { r -= per0; h = 1; if (r >= per1) { r -= per1; h = 2; } }
+            const int cell = r / 3, an = r - cell * 3;
+            const int gw = h == 0 ? a.gw[0] : (h == 1 ? a.gw[1] : a.gw[2]), gh = h == 0 ? a.gh[0] : (h == 1 ? a.gh[1] : a.gh[2]);
+            const int cs = h == 0 ? a.cs[0] : (h == 1 ? a.cs[1] : a.cs[2]);
+            const uint16_t* hp = h == 0 ? a.head[0] : (h == 1 ? a.head[1] : a.head[2]);
+            ptr[k] = hp + ((size_t)img * gh * gw + cell) * cs + an * stride_a;
+            vo[k] = ptr[k][4]; vc[k] = ptr[k][5 + a.cls];
+        }
+        float sc[DET_K];
+        unsigned keep = 0;
+#pragma unroll
+        for (int k = 0; k < DET_K; ++k) {
+            sc[k] = sigmoidf_(bf16_to_f32(vo[k])) * sigmoidf_(bf16_to_f32(vc[k]));
+            if (base + tid * DET_K + k < total && sc[k] > a.score_thresh) keep |= 1u << k;
+        }
+        // ordered compaction: exclusive scan of the per-thread counts over the workgroup (wave scan, wave totals, running base)
+        const int cnt = __popc(keep);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) L.wtot[wave] = incl;
+        __syncthreads();
+        int off = L.running + incl - cnt;
+        for (int w = 0; w < wave; ++w) off += L.wtot[w];
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < DET_K; ++k) {
+                if (!((keep >> k) & 1u)) continue;
+                if (off < PAM_YOLO_MAX_CAND) {
+                    const int q = base + tid * DET_K + k;
+                    int h = 0, r = q;
+                    if (r >= per0) { r -= per0; h = 1; if (r >= per1) { r -= per1; h = 2; } }
+                    const int cell = r / 3, an = r - cell * 3;
+                    const int gw = h == 0 ? a.gw[0] : (h == 1 ? a.gw[1] : a.gw[2]), gh = h == 0 ? a.gh[0] : (h == 1 ? a.gh[1] : a.gh[2]);
+                    const int gy = cell / gw, gx = cell - gy * gw;
+                    const uint16_t* p = ptr[k];
+                    const float bx = (sigmoidf_(bf16_to_f32(p[0])) + (float)gx) / (float)gw;
+                    const float by = (sigmoidf_(bf16_to_f32(p[1])) + (float)gy) / (float)gh;
+                    const float bw = expf(bf16_to_f32(p[2])) * a.anchors[(h * 3 + an) * 2 + 0] / (float)a.net_w;
+                    const float bh = expf(bf16_to_f32(p[3])) * a.anchors[(h * 3 + an) * 2 + 1] / (float)a.net_h;
+                    L.x1[off] = (bx - 0.5f * bw) * (float)a.frame_w; L.x2[off] = (bx + 0.5f * bw) * (float)a.frame_w;
+                    L.y1[off] = (by - 0.5f * bh) * (float)a.frame_h; L.y2[off] = (by + 0.5f * bh) * (float)a.frame_h;
+                    L.sc[off] = sc[k];
+                }
+                ++off;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < DET_T / 64; ++w) t += L.wtot[w]; L.running += t; }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    const int nfound = L.running;
+    const int ncand = nfound < PAM_YOLO_MAX_CAND ? nfound : PAM_YOLO_MAX_CAND;
+    static_assert(PAM_YOLO_MAX_CAND == 64 * 16, "NMS wave holds 16 candidates per lane");
+    int kept;
+    if (ncand <= 64) kept = det_nms_wave<1, true>(a, L, img, ncand, lane);
+    else if (ncand <= 256) kept = det_nms_wave<4, true>(a, L, img, ncand, lane);
+    else kept = det_nms_wave<16, false>(a, L, img, ncand, lane);
+    if (lane == 0) { a.count[img] = kept; a.count[a.n_img + img] = nfound; }
 }
 
 extern "C" int pam_yolo_detect(void* stream, int n_img, const void* const* heads, const int32_t* grid_h, const int32_t* grid_w,

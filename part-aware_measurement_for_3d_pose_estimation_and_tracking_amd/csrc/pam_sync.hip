@@ -9,7 +9,9 @@
 // the usual kernel-boundary acquire).  The poll is BOUNDED: past max_us (2 s in the executor: far beyond any stall of a healthy run,
 // e.g. the context switches of two processes sharing a device) the gate sets *err and lets the stream go on -- a mapping of two chains
 // onto one in-order hardware queue, or a profiler that serialises kernels, cannot hang the device; the host checks err after the first
-// replay of every capture and falls back to stream events (pam/hrnet.py).
+// replay of every capture and falls back to stream events (pam/hrnet.py).  A time-out also stores 1 to *host_err when the caller gave
+// one (a word of pinned host memory: the host reads it before every later replay at no cost to the device), so a time-out in ANY replay
+// is reported -- e.g. two flagged replays in flight at the same time can block each other's queues, which no check of one replay sees.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/pam.h"
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(64) void k_flag_signal(int* counter) {
     }
 }
 
-__global__ __launch_bounds__(64) void k_flag_gate(int* counter, int target, int* err, unsigned max_us, int arrive) {
+__global__ __launch_bounds__(64) void k_flag_gate(int* counter, int target, int* err, unsigned max_us, int arrive, int* host_err) {
     if (threadIdx.x == 0) {
         if (arrive) {                                     // arrive-and-wait: this stream's own contribution, then everybody else's
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(64) void k_flag_gate(int* counter, int target, int*
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)max_us * 100ull) {
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (host_err) __hip_atomic_store(host_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -48,8 +51,8 @@ extern "C" int pam_flag_signal(void* stream, int32_t* dev_counter) {
     hipLaunchKernelGGL(k_flag_signal, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counter);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
-extern "C" int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, int max_us, int arrive) {
+extern "C" int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, int max_us, int arrive, int32_t* host_err) {
     if (!dev_counter || !dev_err || target < 1 || max_us < 1) return PAM_E_ARG;
-    hipLaunchKernelGGL(k_flag_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counter, target, dev_err, (unsigned)max_us, arrive ? 1 : 0);
+    hipLaunchKernelGGL(k_flag_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counter, target, dev_err, (unsigned)max_us, arrive ? 1 : 0, host_err);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

@@ -320,6 +320,10 @@ class HRNetPose(object):
         # that widens with the down-scaling factor (HD Panoptic boxes taller than 384 pixels) -- csrc/pam_image.hip
         self.antialias = bool(antialias)
         self.flag_synced = {}        # (crops, kind, slot) -> the replay orders its branch streams by device-side flags (False: stream events)
+        # a gate that times out in ANY replay stores 1 here (pinned host memory, csrc/pam_sync.hip): read before every replay
+        self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._flag_host_np = self._flag_host.numpy()
+        self.hip.flag_host_err = self._flag_host
         self.flag_timing = None      # the race of the first flagged capture against stream events: dict(crops, flags_ms, events_ms)
         self._dead_graphs = []       # captures that lost that race or failed the flag check (never destroyed: _lib.new_graph)
         self.captures = 0            # hipGraph captures made so far (a capture inside a frame is a stall of hundreds of ms: warm())
@@ -404,6 +408,7 @@ class HRNetPose(object):
                     graph.replay()
                     torch.cuda.synchronize(self.device)
                     keep = int(flags[0].item()) == 0
+                    self._flag_host_np[0] = 0                                             # (a time-out of THIS replay is dealt with here)
                     other_form = None
                     if keep and self.flag_timing is None:
                         # the FIRST flagged capture of this object is raced against the same forward ordered by stream events: under
@@ -426,6 +431,8 @@ class HRNetPose(object):
             g = (graph, static_in, static_out)
             self._graphs[(n, kind, slot)] = g
             self.flag_synced[(n, kind, slot)] = flags is not None
+        if self._flag_host_np[0] != 0:
+            self._flag_timeout()
         graph, static_in, static_out = g
         if static_in.data_ptr() != x.data_ptr():
             static_in.copy_(x)
@@ -440,6 +447,25 @@ class HRNetPose(object):
             e0.record(); graph.replay(); e1.record(); e1.synchronize()
             best = min(best, e0.elapsed_time(e1))
         return best
+
+    def disable_flag_sync(self):
+        """From now on every replay orders its branch streams by stream events; flagged captures leave the cache (kept alive, never
+        destroyed) and are re-captured at their next use.  For callers that keep two forwards in flight at the same time: the gates
+        of two flagged replays can block each other's hardware queues (FramePipeline(pose_streams=2) calls this)."""
+        self._flag_sync_failed = True
+        for key in [k for k, on in self.flag_synced.items() if on]:
+            self._dead_graphs.append(self._graphs.pop(key))
+            self.flag_synced.pop(key)
+
+    def _flag_timeout(self):
+        """A gate of an earlier replay gave up (pam_flag_gate's host word): the forwards replayed since the last check may have read
+        tensors that were not complete.  Flags are off from here on, and the caller is told."""
+        torch.cuda.synchronize(self.device)
+        self._flag_host_np[0] = 0
+        self.disable_flag_sync()
+        raise _lib.PamError('a device-side gate of a captured HRNet forward timed out (flag_max_us = %d us): the keypoints of the forwards '
+                            'since the previous call are not valid; this object orders its branch streams by stream events from now on '
+                            '(were two flagged forwards in flight at the same time?)' % self.hip.flag_max_us)
 
     def _flag_sync_ok(self):
         return bool(self.hip.flag_sync) and not getattr(self, '_flag_sync_failed', False) and os.environ.get('PAM_FLAG_SYNC', '1') != '0'

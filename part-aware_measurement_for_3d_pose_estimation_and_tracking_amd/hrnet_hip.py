@@ -865,6 +865,7 @@ class HipHRNet(ConvEngine):
     # gate that timed out (two chains mapped onto one in-order hardware queue, a profiler serialising kernels) means a re-capture with stream events.
     flag_sync = True            # policy: captured replays use flags (HRNetPose._run); False / PAM_FLAG_SYNC=0: stream events everywhere
     flags_on = False            # state: this forward is being issued with flags
+    flag_host_err = None        # pinned int32 word that receives 1 when a gate of ANY replay times out (HRNetPose reads it before every replay)
     flag_max_us = 2000000       # a gate gives up after 2 s (a systematic deadlock, found by the check after the first replay) and raises the error word
     _flags = None
 
@@ -889,7 +890,8 @@ class HipHRNet(ConvEngine):
 
     def _gate(self, i, target, arrive=False):
         rc = self.lib.pam_flag_gate(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.c_void_p(self._flags.data_ptr() + 4 * i),
-                                    int(target), C.c_void_p(self._flags.data_ptr()), int(self.flag_max_us), 1 if arrive else 0)
+                                    int(target), C.c_void_p(self._flags.data_ptr()), int(self.flag_max_us), 1 if arrive else 0,
+                                    C.c_void_p(self.flag_host_err.data_ptr()) if self.flag_host_err is not None else None)
         if rc != 0:
             raise _lib.PamError('pam_flag_gate failed (%d)' % rc)
 

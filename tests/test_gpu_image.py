@@ -636,3 +636,11 @@ def test_replays_order_their_branch_streams_by_device_flags_and_fall_back_when_a
     torch.cuda.synchronize()
     assert c.flag_synced[(5, 'features', 0)] is False and c.captures == 1 and len(c._dead_graphs) == 1 and torch.equal(ref, y2)
     assert c._flag_sync_ok() is False                   # and the process stays with stream events
+    assert int(c._flag_host_np[0]) == 0                 # the time-outs of the checked replay were dealt with there
+    # a time-out in a LATER replay reaches the host through the pinned word: the next call raises and the object falls back
+    from pam import _lib
+    b._flag_host_np[0] = 1
+    with pytest.raises(_lib.PamError, match='gate'):
+        b.features(x)
+    y4 = b.features(x).clone(); torch.cuda.synchronize()
+    assert b.flag_synced[(5, 'features', 0)] is False and torch.equal(ref, y4)
