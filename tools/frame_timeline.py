@@ -14,7 +14,7 @@ rows.sort(key=lambda r: r[1])
 pre = [i for i, r in enumerate(rows) if 'k_preprocess_crops' in r[0]]
 skip = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 frames = list(zip(pre[skip:-1], pre[skip + 1:]))
-is_conv = lambda n: any(s in n for s in ('k_conv', 'k_bblock', 'k_upsample', 'k_pw', 'k_bneck', 'k_stem_fused'))
+is_conv = lambda n: any(s in n for s in ('k_conv', 'k_bblock', 'k_upsample', 'k_pw', 'k_bneck', 'k_stem_fused', 'k_down', 'k_fuse_sum', 'k_flag'))
 acc = {}
 def add(k, v): acc.setdefault(k, []).append(v / 1e3)
 for a, b in frames:
