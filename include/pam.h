@@ -408,6 +408,15 @@ int pam_yolo_detect(void* stream, int n_img, const void* const* heads /*host arr
                     const int32_t* grid_w, const int32_t* chan_stride, const float* anchors, int net_w, int net_h,
                     int num_classes, int class_id, float score_thresh, float nms_thresh, int frame_w, int frame_h,
                     int max_det, float* dev_out, int32_t* dev_count);
+/* pam_yolo_detect_ws (round 5): the same result with the scoring pass spread over several workgroups per image (2 048 candidates each;
+ * the workgroup that finishes an image last concatenates their kept boxes in candidate order and runs the NMS).  dev_workspace: at least
+ * pam_yolo_detect_workspace_bytes(n_img, grid_h, grid_w) bytes of device memory, 16-byte aligned, whose first 4 * n_img bytes are ZERO
+ * before the first call (the kernel leaves them zero); one workspace serves one call at a time. */
+long long pam_yolo_detect_workspace_bytes(int n_img, const int32_t* grid_h, const int32_t* grid_w);
+int pam_yolo_detect_ws(void* stream, int n_img, const void* const* heads, const int32_t* grid_h, const int32_t* grid_w,
+                       const int32_t* chan_stride, const float* anchors, int net_w, int net_h, int num_classes, int class_id,
+                       float score_thresh, float nms_thresh, int frame_w, int frame_h, int max_det, float* dev_out, int32_t* dev_count,
+                       void* dev_workspace, long long workspace_bytes);
 
 #ifdef __cplusplus
 }

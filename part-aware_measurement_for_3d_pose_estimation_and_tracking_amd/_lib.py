@@ -102,6 +102,8 @@ _SIGS = {
     'pam_resize_frames': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'pam_upsample_concat_nhwc_bf16': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I]),
     'pam_yolo_detect': (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, C.c_float, _I, _I, _I, _P, _P]),
+    'pam_yolo_detect_ws': (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, C.c_float, _I, _I, _I, _P, _P, _P, C.c_longlong]),
+    'pam_yolo_detect_workspace_bytes': (C.c_longlong, [_I, _P, _P]),
 }
 EXPORTS = tuple(_SIGS)
 YOLO_MAX_CAND = 1024        # PAM_YOLO_MAX_CAND in include/pam.h

@@ -232,15 +232,120 @@ __global__ __launch_bounds__(DET_T) void k_yolo_detect(YoloArgs a) {
     if (lane == 0) { a.count[img] = kept; a.count[a.n_img + img] = nfound; }
 }
 
-extern "C" int pam_yolo_detect(void* stream, int n_img, const void* const* heads, const int32_t* grid_h, const int32_t* grid_w,
-                               const int32_t* chan_stride, const float* anchors, int net_w, int net_h, int num_classes,
-                               int class_id, float score_thresh, float nms_thresh, int frame_w, int frame_h, int max_det,
-                               float* dev_out, int32_t* dev_count) {
+// ---- the same decode + NMS with pass 1 spread over several workgroups per image (round 5) ----------------------------------------
+// Pass 1 of k_yolo_detect is one CU's rate for divergent 2-byte loads (10 647 candidates x 2 loads per view: ~35 us of its 56 us).  Here a
+// workgroup of 256 threads scores ONE run of 256 x DET_K consecutive candidates and writes its kept ones, in order, to its segment of
+// a workspace in device memory; the workgroup that takes an image's last ticket (agent-scope release / acquire around an atomic counter:
+// the segments come from other XCDs' L2s) concatenates the segments in run order -- the same candidate order as the one-workgroup
+// kernel -- and runs the same one-wave NMS, with every candidate in registers (four waves per workgroup: 512 VGPRs per lane are there).
+// workspace: [n_img] tickets (zero before the FIRST use; the kernel leaves them zero) | [n_img][runs] counts | [n_img][runs] DetSeg
+struct DetSeg { float x1[PAM_YOLO_MAX_CAND], y1[PAM_YOLO_MAX_CAND], x2[PAM_YOLO_MAX_CAND], y2[PAM_YOLO_MAX_CAND], sc[PAM_YOLO_MAX_CAND]; };
+#define DET_TS 256
+static inline size_t det_ws_head_bytes(int n_img, int runs) { return (((size_t)n_img * (1 + runs) * sizeof(int)) + 255) & ~(size_t)255; }
+
+__global__ __launch_bounds__(DET_TS) void k_yolo_detect_split(YoloArgs a, int* __restrict__ tickets, int* __restrict__ counts, DetSeg* __restrict__ segs) {
+    __shared__ DetLds L;
+    __shared__ int s_last;
+    const int run = blockIdx.x, runs = gridDim.x, img = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per0 = a.gh[0] * a.gw[0] * 3, per1 = a.gh[1] * a.gw[1] * 3, per2 = a.gh[2] * a.gw[2] * 3;
+    const int total = per0 + per1 + per2;
+    const int stride_a = 5 + a.nc;
+    const int base = run * DET_TS * DET_K;
+    DetSeg& seg = segs[(size_t)img * runs + run];
+    {
+        const uint16_t* ptr[DET_K];
+        uint16_t vo[DET_K], vc[DET_K];
+#pragma unroll
+        for (int k = 0; k < DET_K; ++k) {
+            const int q = min(base + tid * DET_K + k, total - 1);
+            int h = 0, r = q;
+            if (r >= per0) { r -= per0; h = 1; if (r >= per1) { r -= per1; h = 2; } }
+            const int cell = r / 3, an = r - cell * 3;
+            const int gw = h == 0 ? a.gw[0] : (h == 1 ? a.gw[1] : a.gw[2]), gh = h == 0 ? a.gh[0] : (h == 1 ? a.gh[1] : a.gh[2]);
+            const int cs = h == 0 ? a.cs[0] : (h == 1 ? a.cs[1] : a.cs[2]);
+            const uint16_t* hp = h == 0 ? a.head[0] : (h == 1 ? a.head[1] : a.head[2]);
+            ptr[k] = hp + ((size_t)img * gh * gw + cell) * cs + an * stride_a;
+            vo[k] = ptr[k][4]; vc[k] = ptr[k][5 + a.cls];
+        }
+        float sc[DET_K];
+        unsigned keep = 0;
+#pragma unroll
+        for (int k = 0; k < DET_K; ++k) {
+            sc[k] = sigmoidf_(bf16_to_f32(vo[k])) * sigmoidf_(bf16_to_f32(vc[k]));
+            if (base + tid * DET_K + k < total && sc[k] > a.score_thresh) keep |= 1u << k;
+        }
+        const int cnt = __popc(keep);
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) L.wtot[wave] = incl;
+        __syncthreads();
+        int off = incl - cnt;
+        for (int w = 0; w < wave; ++w) off += L.wtot[w];
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < DET_K; ++k) {
+                if (!((keep >> k) & 1u)) continue;
+                if (off < PAM_YOLO_MAX_CAND) {
+                    const int q = base + tid * DET_K + k;
+                    int h = 0, r = q;
+                    if (r >= per0) { r -= per0; h = 1; if (r >= per1) { r -= per1; h = 2; } }
+                    const int cell = r / 3, an = r - cell * 3;
+                    const int gw = h == 0 ? a.gw[0] : (h == 1 ? a.gw[1] : a.gw[2]), gh = h == 0 ? a.gh[0] : (h == 1 ? a.gh[1] : a.gh[2]);
+                    const int gy = cell / gw, gx = cell - gy * gw;
+                    const uint16_t* p = ptr[k];
+                    const float bx = (sigmoidf_(bf16_to_f32(p[0])) + (float)gx) / (float)gw;
+                    const float by = (sigmoidf_(bf16_to_f32(p[1])) + (float)gy) / (float)gh;
+                    const float bw = expf(bf16_to_f32(p[2])) * a.anchors[(h * 3 + an) * 2 + 0] / (float)a.net_w;
+                    const float bh = expf(bf16_to_f32(p[3])) * a.anchors[(h * 3 + an) * 2 + 1] / (float)a.net_h;
+                    seg.x1[off] = (bx - 0.5f * bw) * (float)a.frame_w; seg.x2[off] = (bx + 0.5f * bw) * (float)a.frame_w;
+                    seg.y1[off] = (by - 0.5f * bh) * (float)a.frame_h; seg.y2[off] = (by + 0.5f * bh) * (float)a.frame_h;
+                    seg.sc[off] = sc[k];
+                }
+                ++off;
+            }
+        }
+    }
+    // every thread releases its segment stores; the last thread to get there publishes the run's count and takes a ticket
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < DET_TS / 64; ++w) t += L.wtot[w];
+        __hip_atomic_store(&counts[(size_t)img * runs + run], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        s_last = __hip_atomic_fetch_add(&tickets[img], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == runs - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (tid == 0) __hip_atomic_store(&tickets[img], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    int nfound = 0, off = 0;
+    for (int r = 0; r < runs; ++r) {
+        const int c = __hip_atomic_load(&counts[(size_t)img * runs + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int take = min(min(c, PAM_YOLO_MAX_CAND), PAM_YOLO_MAX_CAND - off);
+        const DetSeg& g = segs[(size_t)img * runs + r];
+        for (int i = tid; i < take; i += DET_TS) {
+            L.x1[off + i] = g.x1[i]; L.y1[off + i] = g.y1[i]; L.x2[off + i] = g.x2[i]; L.y2[off + i] = g.y2[i]; L.sc[off + i] = g.sc[i];
+        }
+        nfound += c; off += take;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int ncand = off;
+    int kept;
+    if (ncand <= 64) kept = det_nms_wave<1, true>(a, L, img, ncand, lane);
+    else if (ncand <= 256) kept = det_nms_wave<4, true>(a, L, img, ncand, lane);
+    else kept = det_nms_wave<16, true>(a, L, img, ncand, lane);
+    if (lane == 0) { a.count[img] = kept; a.count[a.n_img + img] = nfound; }
+}
+
+static int det_fill_args(YoloArgs& a, int n_img, const void* const* heads, const int32_t* grid_h, const int32_t* grid_w, const int32_t* chan_stride,
+                         const float* anchors, int net_w, int net_h, int num_classes, int class_id, float score_thresh, float nms_thresh,
+                         int frame_w, int frame_h, int max_det, float* dev_out, int32_t* dev_count) {
     if (n_img < 0 || !heads || !grid_h || !grid_w || !chan_stride || !anchors || !dev_out || !dev_count || num_classes <= 0 ||
         class_id < 0 || class_id >= num_classes || max_det <= 0 || net_w <= 0 || net_h <= 0)
         return PAM_E_ARG;
-    if (n_img == 0) return PAM_OK;
-    YoloArgs a;
     for (int h = 0; h < 3; ++h) {
         if (!heads[h] || grid_h[h] <= 0 || grid_w[h] <= 0 || chan_stride[h] < 3 * (5 + num_classes)) return PAM_E_ARG;
         a.head[h] = (const uint16_t*)heads[h]; a.gh[h] = grid_h[h]; a.gw[h] = grid_w[h]; a.cs[h] = chan_stride[h];
@@ -248,6 +353,46 @@ extern "C" int pam_yolo_detect(void* stream, int n_img, const void* const* heads
     for (int i = 0; i < 18; ++i) a.anchors[i] = anchors[i];
     a.net_w = net_w; a.net_h = net_h; a.nc = num_classes; a.cls = class_id; a.score_thresh = score_thresh; a.nms_thresh = nms_thresh;
     a.frame_w = frame_w; a.frame_h = frame_h; a.max_det = max_det; a.out = dev_out; a.count = dev_count; a.n_img = n_img;
+    return PAM_OK;
+}
+static int det_runs(const int32_t* grid_h, const int32_t* grid_w) {
+    long long total = 0;
+    for (int h = 0; h < 3; ++h) total += (long long)grid_h[h] * grid_w[h] * 3;
+    return (int)((total + DET_TS * DET_K - 1) / (DET_TS * DET_K));
+}
+extern "C" long long pam_yolo_detect_workspace_bytes(int n_img, const int32_t* grid_h, const int32_t* grid_w) {
+    if (n_img < 0 || !grid_h || !grid_w) return -1;
+    for (int h = 0; h < 3; ++h) if (grid_h[h] <= 0 || grid_w[h] <= 0) return -1;
+    const int runs = det_runs(grid_h, grid_w);
+    return (long long)(det_ws_head_bytes(n_img, runs) + (size_t)n_img * runs * sizeof(DetSeg));
+}
+extern "C" int pam_yolo_detect_ws(void* stream, int n_img, const void* const* heads, const int32_t* grid_h, const int32_t* grid_w,
+                                  const int32_t* chan_stride, const float* anchors, int net_w, int net_h, int num_classes,
+                                  int class_id, float score_thresh, float nms_thresh, int frame_w, int frame_h, int max_det,
+                                  float* dev_out, int32_t* dev_count, void* dev_workspace, long long workspace_bytes) {
+    YoloArgs a;
+    const int rc = det_fill_args(a, n_img, heads, grid_h, grid_w, chan_stride, anchors, net_w, net_h, num_classes, class_id, score_thresh,
+                                 nms_thresh, frame_w, frame_h, max_det, dev_out, dev_count);
+    if (rc != PAM_OK) return rc;
+    if (n_img == 0) return PAM_OK;
+    if (!dev_workspace || workspace_bytes < pam_yolo_detect_workspace_bytes(n_img, grid_h, grid_w) || ((uintptr_t)dev_workspace & 15)) return PAM_E_ARG;
+    const int runs = det_runs(grid_h, grid_w);
+    int* tickets = (int*)dev_workspace;
+    int* counts = tickets + n_img;
+    DetSeg* segs = (DetSeg*)((char*)dev_workspace + det_ws_head_bytes(n_img, runs));
+    hipLaunchKernelGGL(k_yolo_detect_split, dim3(runs, n_img), dim3(DET_TS), 0, (hipStream_t)stream, a, tickets, counts, segs);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+
+extern "C" int pam_yolo_detect(void* stream, int n_img, const void* const* heads, const int32_t* grid_h, const int32_t* grid_w,
+                               const int32_t* chan_stride, const float* anchors, int net_w, int net_h, int num_classes,
+                               int class_id, float score_thresh, float nms_thresh, int frame_w, int frame_h, int max_det,
+                               float* dev_out, int32_t* dev_count) {
+    YoloArgs a;
+    const int rc = det_fill_args(a, n_img, heads, grid_h, grid_w, chan_stride, anchors, net_w, net_h, num_classes, class_id, score_thresh,
+                                 nms_thresh, frame_w, frame_h, max_det, dev_out, dev_count);
+    if (rc != PAM_OK) return rc;
+    if (n_img == 0) return PAM_OK;
     hipLaunchKernelGGL(k_yolo_detect, dim3(n_img), dim3(DET_T), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

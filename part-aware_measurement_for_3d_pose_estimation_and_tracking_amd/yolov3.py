@@ -363,6 +363,7 @@ class YOLOv3(object):
         self.net = HipDarknet(model, self.device)
         self.use_graph = use_graph
         self._graphs, self._pool = {}, None
+        self._det_ws = {}            # views per call -> workspace of pam_yolo_detect_ws (zeroed once; the kernel leaves its tickets zero)
 
     # -- device path ---------------------------------------------------------------------------------------------------------
     def _run(self, ptrs, n, fh, fw, x8, boxes, count):
@@ -376,11 +377,17 @@ class YOLOv3(object):
         gh = (C.c_int32 * 3)(*[h.shape[2] for h in heads]); gw = (C.c_int32 * 3)(*[h.shape[3] for h in heads])
         cs = (C.c_int32 * 3)(*[h.shape[1] for h in heads])
         an = np.ascontiguousarray(self.anchors.reshape(-1))
-        rc = self.lib.pam_yolo_detect(C.c_void_p(st), n, hp, gh, gw, cs, an.ctypes.data_as(C.c_void_p), W, H, self.num_classes,
-                                      self.class_id, self.score_thresh, self.nms_thresh, fw, fh, self.max_det,
-                                      C.c_void_p(boxes.data_ptr()), C.c_void_p(count.data_ptr()))
+        # decode + NMS with the scoring pass over several workgroups per image; the workspace belongs to (this detector, n): replays of one
+        # detector run one after the other on its stream
+        need = int(self.lib.pam_yolo_detect_workspace_bytes(n, gh, gw))
+        ws = self._det_ws.get(n)
+        if ws is None or ws.numel() < need:
+            ws = self._det_ws[n] = torch.zeros(need, dtype=torch.uint8, device=self.device)
+        rc = self.lib.pam_yolo_detect_ws(C.c_void_p(st), n, hp, gh, gw, cs, an.ctypes.data_as(C.c_void_p), W, H, self.num_classes,
+                                         self.class_id, self.score_thresh, self.nms_thresh, fw, fh, self.max_det,
+                                         C.c_void_p(boxes.data_ptr()), C.c_void_p(count.data_ptr()), C.c_void_p(ws.data_ptr()), need)
         if rc != 0:
-            raise _lib.PamError('pam_yolo_detect failed: %d' % rc)
+            raise _lib.PamError('pam_yolo_detect_ws failed: %d' % rc)
         return heads
 
     def detect_dev(self, frames):

@@ -106,7 +106,7 @@ def test_upsample_concat_vs_oracle():
     assert rc == -1                                              # odd output height: PAM_E_ARG
 
 
-def _run_detect(heads_np, anchors, net, nc, cls, st, nt, fw, fh, max_det):
+def _run_detect(heads_np, anchors, net, nc, cls, st, nt, fw, fh, max_det, split=False):
     from pam import _lib
     n = heads_np[0].shape[0]
     hd = [torch.from_numpy(h).to(torch.bfloat16).to(DEV).contiguous() for h in heads_np]
@@ -115,8 +115,23 @@ def _run_detect(heads_np, anchors, net, nc, cls, st, nt, fw, fh, max_det):
     an = np.ascontiguousarray(anchors.reshape(-1), dtype=np.float32)
     boxes = torch.full((n, max_det, 5), -1.0, dtype=torch.float32, device=DEV)
     count = torch.full((2 * n,), -1, dtype=torch.int32, device=DEV)
-    rc = _lib.load().pam_yolo_detect(None, n, hp, gh, gw, cs, an.ctypes.data_as(C.c_void_p), net[0], net[1], nc, cls, st, nt, fw, fh,
-                                     max_det, C.c_void_p(boxes.data_ptr()), C.c_void_p(count.data_ptr()))
+    lib = _lib.load()
+    if split:
+        # the scoring pass over several workgroups per image; the SAME workspace twice: the kernel must leave its tickets zero
+        need = lib.pam_yolo_detect_workspace_bytes(n, gh, gw)
+        assert need > 0
+        ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+        args = (None, n, hp, gh, gw, cs, an.ctypes.data_as(C.c_void_p), net[0], net[1], nc, cls, st, nt, fw, fh, max_det)
+        scratch_boxes, scratch_count = torch.empty_like(boxes), torch.empty_like(count)
+        assert lib.pam_yolo_detect_ws(*args, C.c_void_p(scratch_boxes.data_ptr()), C.c_void_p(scratch_count.data_ptr()), C.c_void_p(ws.data_ptr()), need) == 0
+        rc = lib.pam_yolo_detect_ws(*args, C.c_void_p(boxes.data_ptr()), C.c_void_p(count.data_ptr()), C.c_void_p(ws.data_ptr()), need)
+        assert lib.pam_yolo_detect_ws(*args, C.c_void_p(boxes.data_ptr()), C.c_void_p(count.data_ptr()), C.c_void_p(ws.data_ptr()), need - 1) == -1
+        assert lib.pam_yolo_detect_ws(*args, C.c_void_p(boxes.data_ptr()), C.c_void_p(count.data_ptr()), None, need) == -1
+        torch.cuda.synchronize()
+        assert int(ws[:4 * n].view(torch.int32).abs().sum()) == 0
+    else:
+        rc = lib.pam_yolo_detect(None, n, hp, gh, gw, cs, an.ctypes.data_as(C.c_void_p), net[0], net[1], nc, cls, st, nt, fw, fh,
+                                 max_det, C.c_void_p(boxes.data_ptr()), C.c_void_p(count.data_ptr()))
     assert rc == 0
     torch.cuda.synchronize()
     return boxes.cpu().numpy(), count.cpu().numpy(), [h.float().cpu().numpy() for h in hd]
@@ -129,7 +144,8 @@ def _run_detect(heads_np, anchors, net, nc, cls, st, nt, fw, fh, max_det):
     (1, (4, 8, 16), 1, 24, 0, 0.2, 0.5, 100, 1.0),           # tiny grids, low threshold: > 1024 candidates are counted, 1024 enter
     (2, (5, 9, 19), 3, 32, 2, 0.999999, 0.45, 16, 1.0),      # nothing passes
 ])
-def test_yolo_detect_vs_oracle(cfg):
+@pytest.mark.parametrize('split', [False, True])
+def test_yolo_detect_vs_oracle(cfg, split):
     from pam import yolov3
     n, grids, nc, cs, cls, st, nt, max_det, sigma = cfg
     rng = np.random.default_rng(3)
@@ -138,7 +154,7 @@ def test_yolo_detect_vs_oracle(cfg):
     if cfg[1] == (4, 8, 16):
         for h in heads:
             h[..., 4::(5 + nc)] += 4.0; h[..., 5::(5 + nc)] += 4.0
-    boxes, count, hq = _run_detect(heads, anchors, (416, 448), nc, cls, st, nt, 1032, 776, max_det)
+    boxes, count, hq = _run_detect(heads, anchors, (416, 448), nc, cls, st, nt, 1032, 776, max_det, split)
     for i in range(n):
         exp, nfound = Y.detect([h[i] for h in hq], anchors, 416, 448, nc, cls, st, nt, 1032, 776, max_det)
         assert count[n + i] == nfound, (i, count[n + i], nfound)
