@@ -503,6 +503,9 @@ def main():
     single_dev = os.environ.get('PAM_BENCH_SINGLE_DEVICE') == '1'
     if single_dev:
         local_rank = 0
+        # ranks sharing ONE device: the device-side gates of one process's replays and the queues of the other process oversubscribe the
+        # hardware queue slots, and a gate has been seen to wait out its 2 s bound there (round 5) -> stream events in this mode
+        os.environ['PAM_FLAG_SYNC'] = '0'
     backend = os.environ.get('PAM_BENCH_BACKEND', 'nccl')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

@@ -324,6 +324,8 @@ class HRNetPose(object):
         self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self._flag_host_np = self._flag_host.numpy()
         self.hip.flag_host_err = self._flag_host
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > torch.cuda.device_count():
+            self._flag_sync_failed = True                 # ranks share a device: stream events (see FramePipeline)
         self.flag_timing = None      # the race of the first flagged capture against stream events: dict(crops, flags_ms, events_ms)
         self._dead_graphs = []       # captures that lost that race or failed the flag check (never destroyed: _lib.new_graph)
         self.captures = 0            # hipGraph captures made so far (a capture inside a frame is a stall of hundreds of ms: warm())

@@ -69,8 +69,10 @@ class FramePipeline(object):
         assert pose_streams in (1, 2) and (pose_streams == 1 or overlap_tracker), 'two pose streams need the tracker on its own stream'
         self.pose_streams = [torch.cuda.Stream(self.device) for _ in range(pose_streams)] if pose_streams > 1 else None
         self._frame_no = 0
-        if self.pose_streams is not None and self.net is not None:
-            self.net.disable_flag_sync()     # two forwards in flight: the device-side gates of one can block the other's queues (pam_sync.hip)
+        # device-side gates (pam_sync.hip) need the forward to be the only flagged work on the device: two forwards in flight can block
+        # each other's queues, and so can the replays of several ranks that share one device (more ranks than devices: one-device tests)
+        if self.net is not None and (self.pose_streams is not None or world > torch.cuda.device_count()):
+            self.net.disable_flag_sync()
         self.bucketed, self.warmed = bool(prewarm), None
         if prewarm and self.net is not None:
             most = (self.C if shard == 'crops' else len(self.mine)) * max_dets
