@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Stress of the device-side flag synchronisation (development tool): replays of several crop counts / executor configurations, the
+host error word checked at the end of each; --procs 2 runs two processes on the same device at the same time."""
+import os, sys, argparse, subprocess, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ap = argparse.ArgumentParser()
+ap.add_argument('--counts', default='4,10,12,20,35'); ap.add_argument('--replays', type=int, default=300); ap.add_argument('--procs', type=int, default=1)
+ap.add_argument('--child', action='store_true')
+args = ap.parse_args()
+if args.procs > 1 and not args.child:
+    ps = [subprocess.Popen([sys.executable, __file__, '--counts', args.counts, '--replays', str(args.replays), '--child']) for _ in range(args.procs)]
+    sys.exit(max(p.wait() for p in ps))
+import torch
+import pam
+from pam import hrnet
+net = hrnet.HRNetPose(48, 17, None, use_graph=True, autotune=True, max_crops=40)
+bad = 0
+for n in [int(c) for c in args.counts.split(',')]:
+    x = net.input_buffer(n)
+    x.normal_()
+    t0 = time.perf_counter()
+    net.features(x); torch.cuda.synchronize()
+    for _ in range(args.replays):
+        net.features(x)
+    torch.cuda.synchronize()
+    err = int(net._flag_host_np[0])
+    bad += err
+    print('pid %d  n=%d  config=%s  flags=%s  host error word=%d  %.2f ms/replay' % (os.getpid(), n, net.tuned[n]['choice'], net.flag_synced[(n, 'features', 0)], err,
+          (time.perf_counter() - t0) / (args.replays + 1) * 1e3), flush=True)
+    net._flag_host_np[0] = 0
+sys.exit(1 if bad else 0)
