@@ -100,6 +100,9 @@ __device__ __forceinline__ void conv_pass(f32x4 (&acc)[MW1][3], const char* wl, 
     auto ld = [&](int st, bf16x8* a_, bf16x8* b_) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) a_[j] = *(const bf16x8*)(wl + st * SUB + j * 1024);
+#ifdef PAM_KO_PIXREADS                                     // timing knock-out (wrong results): pixel fragments read every third k-step only
+        if (st % 3 == 0)
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i) b_[i] = *(const bf16x8*)(xl + koff[st] + i * TST);
     };
@@ -454,6 +457,9 @@ __global__ __launch_bounds__(64 * B96_NW) void k_bblock2_96(BB96Args a) {
                     af[j] = wrow(s + 1, j);
 #pragma unroll
                     for (int k = 0; k < BPG; ++k)
+#ifdef PAM_KO_PIXREADS
+                        if ((st + 1) % 3 == 0)
+#endif
                         if (j * BPG + k < MT) bf[nxt][j * BPG + k] = xfrag(s + 1, j * BPG + k);
                 }
             }

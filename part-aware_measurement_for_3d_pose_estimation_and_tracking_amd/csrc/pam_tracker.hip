@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <limits.h>
 #include <string>
 #include "pam_device.hpp"
@@ -903,6 +904,14 @@ static int launch_frame(PamHandle* h, hipStream_t s, int frame_id, const int* d_
     const int block = h->d.C > 8 ? 1024 : BLOCK;
     // each workgroup size is its own instantiation with its own __launch_bounds__: under a shared bound of 1024 the 256-thread
     // form was held to 128 VGPRs (occupancy 4) and spilled 211 SGPRs
+#ifdef PAM_DIAG
+    static const int dblock = getenv("PAM_FRAME_BLOCK") ? atoi(getenv("PAM_FRAME_BLOCK")) : 0;
+    static const int dlds = getenv("PAM_FRAME_LDS") ? atoi(getenv("PAM_FRAME_LDS")) : 1;
+    if (!dlds) A.hot_in_lds = 0;
+    if (getenv("PAM_FRAME_VERBOSE")) fprintf(stderr, "k_frame: hot bytes %zu, block %d\n", hot, dblock ? dblock : block);
+    if (dblock == 64) { hipLaunchKernelGGL(k_frame<64>, dim3(h->d.S), dim3(64), A.hot_in_lds ? hot : 0, s, A); HIPCHK(h, hipGetLastError()); return PAM_OK; }
+    if (dblock == 128) { hipLaunchKernelGGL(k_frame<128>, dim3(h->d.S), dim3(128), A.hot_in_lds ? hot : 0, s, A); HIPCHK(h, hipGetLastError()); return PAM_OK; }
+#endif
     if (block == 1024) hipLaunchKernelGGL(k_frame<1024>, dim3(h->d.S), dim3(1024), A.hot_in_lds ? hot : 0, s, A);
     else hipLaunchKernelGGL(k_frame<BLOCK>, dim3(h->d.S), dim3(BLOCK), A.hot_in_lds ? hot : 0, s, A);
     HIPCHK(h, hipGetLastError());
