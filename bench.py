@@ -619,7 +619,7 @@ def main():
                        'branch_sync_race_ms': (pipe.net.flag_timing if pipe.net is not None else None),
                        'exchange': ('one all-gather per frame (%s)' % ('pam_allgather_keypoints: RCCL called inside the C ABI' if pipe.comm else 'torch.distributed ' + backend)) if world > 1 else 'none',
                        'devices': '%d ranks on ONE device (no multi-GPU box: functional check only)' % world if single_dev and world > 1 else '%d' % world},
-            'roofline': {'kernel': 'HRNet-W48 conv stack: k_stem_fused / k_bneck / k_bblock2_48 / k_bblock2_96 / k_conv3x3[s] / k_down48 / k_down_s / k_conv_gs / k_upsample_add '
+            'roofline': {'kernel': 'HRNet-W48 conv stack: k_stem_fused / k_bneck / k_bblock2_48 / k_bblock2_96 / k_conv3x3[s] / k_down48 / k_down_s / k_conv_gs / k_fuse_sum / k_upsample_add '
                                    '(hipGraph replay, %d crops, %d launches, executor configuration %s)' % (n_med, launches, work[n_med]['config'] if n_med in work else None),
                          # this group is a dense contraction -> priced against the bf16 MFMA peak (algorithmic FLOPs / replay time)
                          'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',

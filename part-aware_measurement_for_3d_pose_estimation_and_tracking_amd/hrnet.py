@@ -543,17 +543,20 @@ class HRNetPose(object):
 
     def config_for(self, n):
         """Executor configuration of the n-crop forward (HipHRNet.CONFIGS).  With ``autotune`` a fixed rule from interleaved A/B runs over
-        crop counts (tools/ab_flags.py fused:block2=3 res48:block2=1, end of round 4): from 8 to 12 crops the 96-channel branch runs as
-        streamed convolutions (-0.4 ... -1.3 %: a 64- to 96-item fused launch is a longer chain than it is worth on a half-empty chip);
-        below (2-6 crops: +1.3 ... +3.3 % for that form) and above (16: +3.0 %) both fine branches are fused; round 5: up to 6 crops the
-        fuse-layer sums also carry their 1x1 products (k_fuse_sum: -1.7 ... -1.9 % there, a loss from 12 crops on).  (Round 3 timed every
-        configuration at the first replay of a crop count: 1.5 s per count, a choice decided by noise -- the configurations were 0.4-3 %
-        apart -- and three dead captures per count that could never be destroyed, see _lib.new_graph.)"""
+        crop counts with the branch streams ordered by device-side flags (tools/ab_flags.py fused:flags_on=1 res48:flags_on=1,block2=1
+        fsum:flags_on=1,fused_sums=1, end of round 5): up to 20 crops the fuse-layer sums carry their 1x1 products (k_fuse_sum, 18 launches
+        fewer: 2-6 crops -3.0 ... -3.4 %, 8-16 crops -0.6 ... +0.7 %, 18 crops -1.3 %, 20 crops -1.7 %), above that they are separate launches
+        (22 crops 0.0 %, 24 +0.5 %, 28 +1.6 %: the 1x1 launches hide beside the other branches' blocks and the sums are on the critical path).
+        The 96-channel branch as streamed convolutions (round 4's choice for 8-12 crops under stream events) loses at every count now
+        (+0.1 ... +5.6 %).  (Round 3 timed every configuration at the first replay of a crop count: 1.5 s per count, a choice decided by
+        noise, and three dead captures per count that could never be destroyed, see _lib.new_graph.)"""
         name = type(self.hip).config_name
         if self.autotune:
-            name = 'fused48_fused96_fsum' if n <= 6 else ('resident48_streamed96' if 8 <= n <= 12 else name)
+            name = 'fused48_fused96_fsum' if n <= self.fsum_max_crops else name
         self.tuned[n] = {'choice': name}
         return name
+
+    fsum_max_crops = int(os.environ.get('PAM_FSUM_MAX', '20'))      # tuning hook of config_for's rule
 
     def input_buffer(self, n, slot=0):
         """The (N,3,H,W) channels-last bf16 tensor the preprocessing kernel writes; the replay's own input when one

@@ -554,14 +554,14 @@ def test_configuration_follows_the_crop_count_and_stays_consistent():
     y2 = b.features(x).clone()
     y3 = b.features(x, slot=1).clone()
     torch.cuda.synchronize()
-    assert b.tuned[9]['choice'] == 'resident48_streamed96' and a.tuned[9]['choice'] == hrnet_hip.HipHRNet.config_name == 'fused48_fused96'
-    assert b.config_for(4) == 'fused48_fused96_fsum' and b.config_for(16) == 'fused48_fused96'          # up to 6 crops: fused sums (round 5)
+    assert b.tuned[9]['choice'] == 'fused48_fused96_fsum' and a.tuned[9]['choice'] == hrnet_hip.HipHRNet.config_name == 'fused48_fused96'
+    assert b.config_for(4) == 'fused48_fused96_fsum' and b.config_for(20) == 'fused48_fused96_fsum' and b.config_for(21) == 'fused48_fused96'   # up to 20 crops: fused sums (round 5)
     assert torch.equal(y1, y2) and torch.equal(y1, y3)
     assert float((y1.float() - ref).norm() / ref.norm()) < 1e-2
-    x20 = b.input_buffer(20)
-    x20.copy_(torch.randn(x20.shape, device=x20.device).to(x20.dtype)); x20[:, 3:] = 0
-    b.features(x20); torch.cuda.synchronize()
-    assert b.tuned[20]['choice'] == 'fused48_fused96' and set(c['choice'] for c in b.tuned.values()) <= set(hrnet_hip.HipHRNet.CONFIGS)
+    x24 = b.input_buffer(24)
+    x24.copy_(torch.randn(x24.shape, device=x24.device).to(x24.dtype)); x24[:, 3:] = 0
+    b.features(x24); torch.cuda.synchronize()
+    assert b.tuned[24]['choice'] == 'fused48_fused96' and set(c['choice'] for c in b.tuned.values()) <= set(hrnet_hip.HipHRNet.CONFIGS)
 
 
 def test_preprocess_bucket_padding_repeats_the_last_crop(net):
