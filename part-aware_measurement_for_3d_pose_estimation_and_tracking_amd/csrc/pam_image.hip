@@ -42,11 +42,27 @@ __global__ __launch_bounds__(256) void k_preprocess_crops(int n_src, const uint8
         const float fx = sx - (float)x0, fy = sy - (float)y0;
         const uint8_t* r0 = img + ((size_t)y0 * W) * 3;
         const uint8_t* r1 = img + ((size_t)y1 * W) * 3;
+        // the two pixels of a row are 6 consecutive bytes: ONE unaligned 8-byte load per row instead of six byte loads (the kernel was bound by
+        // the texture-address unit: 12 one-byte gathers per output pixel); not for the last two columns (x1 is clamped there / the load would
+        // leave the row)
+        uint8_t t0[6], t1[6];
+        if (x0 + 2 < W) {
+            struct __attribute__((packed)) U8 { uint32_t x, y; };              // alignment 1: the backend emits one dwordx2 load (unaligned access is on)
+            const U8 q0 = *(const U8*)(r0 + x0 * 3), q1 = *(const U8*)(r1 + x0 * 3);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                t0[k] = (uint8_t)((k < 4 ? q0.x >> (8 * k) : q0.y >> (8 * (k - 4))) & 0xff);
+                t1[k] = (uint8_t)((k < 4 ? q1.x >> (8 * k) : q1.y >> (8 * (k - 4))) & 0xff);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { t0[k] = r0[x0 * 3 + k]; t0[3 + k] = r0[x1 * 3 + k]; t1[k] = r1[x0 * 3 + k]; t1[3 + k] = r1[x1 * 3 + k]; }
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {          // c indexes RGB; source is BGR
             const int sc = 2 - c;
-            const float a = (float)r0[x0 * 3 + sc], b = (float)r0[x1 * 3 + sc];
-            const float cc = (float)r1[x0 * 3 + sc], d = (float)r1[x1 * 3 + sc];
+            const float a = (float)t0[sc], b = (float)t0[3 + sc];
+            const float cc = (float)t1[sc], d = (float)t1[3 + sc];
             const float top = a + (b - a) * fx, bot = cc + (d - cc) * fx;
             const float v = (top + (bot - top) * fy) * (1.0f / 255.0f);
             o[c] = f32_to_bf16((v - mean[c]) * istd[c]);
