@@ -937,7 +937,8 @@ class HipHRNet(ConvEngine):
                 if mg is not None:                                    # first conv of all down chains from this branch in one launch
                     y = self.conv(mg['op'], x, relu=True, relu_from=mg['relu_from'])
                     heads = {i: y[:, off:off + c] for i, off, c, _ in mg['parts']}
-                mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up and not self.fused_sums) else None
+                fmask = 15 if self.fused_sums is True else int(self.fused_sums)   # bit i: output i's sum carries its 1x1 products (k_fuse_sum)
+                mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up and not fmask) else None
                 if mu is not None:                                    # all 1x1 up-convolutions from this branch in one launch
                     if self.knock_up and b == len(mod['branches']) - 1:   # diagnostics: what the last finisher's tail is worth
                         y = self._new(x.shape[0], mu['op'].cout, x.shape[2], x.shape[3], x.device)
@@ -947,7 +948,7 @@ class HipHRNet(ConvEngine):
                         terms[i][b] = (y[:, off:off + c], sh)
                 for i, row in enumerate(fuse):
                     f = row[b] if b < len(row) else None
-                    if f is None or (f[0] == 'up' and (mu is not None or self.fused_sums)):
+                    if f is None or (f[0] == 'up' and (mu is not None or (fmask >> i) & 1)):
                         continue
                     if f[0] == 'up':
                         terms[i][b] = (self.conv(f[1], x), f[2])
@@ -970,7 +971,7 @@ class HipHRNet(ConvEngine):
                 if flags:
                     self._gate(ctail, len(mod['branches']), arrive=True)   # this stream's chain is done; wait for every other branch's
                 tl = [terms[i][j] for j in sorted(terms[i])]
-                fs = mod['fsum'][i] if self.fused_sums else None
+                fs = mod['fsum'][i] if ((15 if self.fused_sums is True else int(self.fused_sums)) >> i) & 1 else None
                 if fs is not None:                                    # plain (down-chain) terms + the coarser branches through their 1x1 products
                     out[i] = self.fuse_sum(fs['op'], xs[i], [t for t, _ in tl], [xs[j] for j in fs['srcs']], relu=True, max_wg=self.fs_cap[i])
                 else:
