@@ -390,7 +390,14 @@ def full_pipeline_runs(torch, dist, pipe, inp, K, W, C, fh, fw, dev, ref_tracks)
         ts.append(a.elapsed_time(b))
     det_ms = float(np.median(ts))
 
-    def run(overlap):
+    # throughput mode of the detector (like value_2frames_per_forward for the pose network): the views of frames t + 1 AND t + 2 in one
+    # detector replay every other frame (2 C views per launch: the 80-launch chain is paid once per two frames)
+    buf2 = det.frame_buffer(2 * C, fh, fw)
+    buf2[:C].copy_(frames); buf2[C:].copy_(frames)
+    det.detect_dev(buf2)
+    torch.cuda.synchronize()
+
+    def run(overlap, pair=False):
         pipe.handle.reset()
 
         def step(t, ev=None):
@@ -398,7 +405,8 @@ def full_pipeline_runs(torch, dist, pipe, inp, K, W, C, fh, fw, dev, ref_tracks)
             with pipe.frame():
                 if overlap:
                     pipe.wait_detection()                                   # frame t's boxes exist (issued a frame ago)
-                    pipe.pose_step_crops(ptrs, e['vl'], e['sl'], e['bx'], ev, lambda: pipe.detect_ahead(buf))
+                    ahead = (lambda: pipe.detect_ahead(buf)) if not pair else ((lambda: pipe.detect_ahead(buf2)) if (t & 1) == 0 else None)
+                    pipe.pose_step_crops(ptrs, e['vl'], e['sl'], e['bx'], ev, ahead)
                 else:
                     det.detect_dev(buf)
                     pipe.pose_step_crops(ptrs, e['vl'], e['sl'], e['bx'], ev)
@@ -412,8 +420,9 @@ def full_pipeline_runs(torch, dist, pipe, inp, K, W, C, fh, fw, dev, ref_tracks)
                 'final_tracks_equal': [t['track_id'] for t in fin['tracks'] if t['emitted']] == ref_tracks, 'clock_mhz': fin['clock_mhz']}
     serial = run(False)
     over = run(True)
-    base_ms = None
+    over2 = run(True, pair=True)
     return {'value': over['value'], 'ms_per_step': over['ms_per_step'], 'serial': serial, 'overlapped': over,
+            'overlapped_two_frames_per_detection': over2,
             'detector_stream_on_its_own_hw_queue': bool(pipe.det_overlaps), 'detector_stream_pick': pipe.det_pick,
             'detector': {'kernel': 'k_resize_frames + Darknet-53 (k_conv_stem / k_conv3x3 / k_conv_igemm, leaky + shortcut epilogues) + k_upsample_concat + k_yolo_detect: '
                                    'one hipGraph replay, %d launches, %d views %dx%d -> %dx%d, random weights' % (dlaunch, C, fw, fh, Wn, H),
