@@ -241,6 +241,10 @@ int pam_conv3x3_layout_ex(int H, int W, int Cin, int Cout, int c96_slab);
  * rows that fit the patch), else 0.  The caller then packs the streamed image for slabs of that width and launches with tile_cfg -7 (any other tile_cfg keeps such layers on
  * the classic kernel and image). */
 int pam_conv3x3_layout_gen(int H, int W, int Cin, int Cout);
+/* round 5: 192- / 384-channel ReLU / linear 3x3 layers with 32-channel slabs (tile_cfg -8 of pam_conv2d_nhwc_bf16_ex; w_img packed as
+ * above for slabs of 32): twice the workgroups, each half as long -- for forwards of a few crops, whose launches are as long as one
+ * workgroup.  Same arithmetic and summation order as the 64-channel-slab form (bit-identical).  > 0: supported, the slab width (32). */
+int pam_conv3x3_layout_small(int H, int W, int Cin, int Cout);
 /* which kernel the calling thread's last pam_conv2d_nhwc_bf16[_ex] call launched (labels for per-kernel profiles) */
 #define PAM_CONV_KERNEL_IGEMM 0   /* k_conv_igemm */
 #define PAM_CONV_KERNEL_3X3   1   /* k_conv3x3   */

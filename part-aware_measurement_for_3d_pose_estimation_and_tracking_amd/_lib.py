@@ -72,6 +72,7 @@ _SIGS = {
     'pam_conv_last_kernel': (_I, []),
     'pam_conv3x3_layout_ex': (_I, [_I, _I, _I, _I, _I]),
     'pam_conv3x3_layout_gen': (_I, [_I, _I, _I, _I]),
+    'pam_conv3x3_layout_small': (_I, [_I, _I, _I, _I]),
     'pam_conv_debug_stamps': (_I, [_P]),
     'pam_upsample_add_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I]),
     'pam_upsample_add_nhwc_bf16_ex': (_I, [_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I]),

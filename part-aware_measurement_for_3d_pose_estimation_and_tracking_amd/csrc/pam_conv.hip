@@ -874,7 +874,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3Args a) {
                                                                        __builtin_bit_cast(bf16x8_t, af[cur][i]), acc[i][j], 0, 0, 0);
             // issue order inside the step: the next step's MT + NTW fragment reads spread between this step's MFMAs (a burst of reads
             // ahead of the MFMAs holds the wave's issue slot ~100 cycles per step with the matrix pipe idle)
-            c3s_spread<MT * NTW, MT + NTW>(std::make_integer_sequence<int, MT + NTW>{});
+            if constexpr (MT * NTW >= MT + NTW) c3s_spread<MT * NTW, MT + NTW>(std::make_integer_sequence<int, MT + NTW>{});   // (16-channel slabs: more reads than MFMAs, the compiler's order)
             __builtin_amdgcn_sched_barrier(0);
         }
         C3_STAMP(4 + 3 * (k & 15));
@@ -1006,6 +1006,11 @@ extern "C" int pam_conv3x3_layout_ex(int H, int W, int Cin, int Cout, int c96_sl
     return c3s_pick(H, W, Cin, Cout, th, mt, pmax, ntw, c96_slab) ? 16 * ntw : 0;
 }
 extern "C" int pam_conv3x3_layout(int H, int W, int Cin, int Cout) { return pam_conv3x3_layout_ex(H, W, Cin, Cout, 0); }
+// 32 = this 192- / 384-channel layer can also run with 32-channel slabs (tile_cfg -8 of pam_conv2d_nhwc_bf16_ex; image packed for that width)
+extern "C" int pam_conv3x3_layout_small(int H, int W, int Cin, int Cout) {
+    int th, mt, pmax, ntw;
+    return ((Cin == 192 || Cin == 384) && Cout % 64 == 0 && c3s_pick(H, W, Cin, Cout, th, mt, pmax, ntw, 0) && pmax != 448) ? 32 : 0;
+}
 template <int CIN, int NTW, int MT, int PMAX, int NBUF>
 static int launch_c3s_one(hipStream_t s, const C3Args& a) {
     constexpr size_t lds = (size_t)NBUF * (PMAX * 64 + 9 * 16 * NTW * 64);
@@ -1043,6 +1048,14 @@ static int launch_c3s(hipStream_t s, const C3Args& a, int Cin, int ntw, int mt, 
         case 38443: return launch_c3s_one<384, 4, 3, 192, 3>(s, a);
         case 38444: return launch_c3s_one<384, 4, 4, 320, 2>(s, a);
         case 38445: return launch_c3s_one<384, 4, 5, 384, 2>(s, a);
+        // 32-channel slabs (tile_cfg -8: forwards of a few crops, where a launch is as long as ONE workgroup): twice the workgroups, half
+        // the MFMAs and 18 instead of 36 KB of weights per chunk each, three chunk buffers
+        case 19223: return launch_c3s_one<192, 2, 3, 192, 3>(s, a);
+        case 19224: return launch_c3s_one<192, 2, 4, 320, 3>(s, a);
+        case 19225: return launch_c3s_one<192, 2, 5, 384, 3>(s, a);
+        case 38423: return launch_c3s_one<384, 2, 3, 192, 3>(s, a);
+        case 38424: return launch_c3s_one<384, 2, 4, 320, 3>(s, a);
+        case 38425: return launch_c3s_one<384, 2, 5, 384, 3>(s, a);
     }
     return PAM_E_ARG;
 }
@@ -1386,6 +1399,23 @@ extern "C" int pam_conv2d_nhwc_bf16_ex(void* stream, const void* in, const void*
 #endif
         CONV_KIND(PAM_CONV_KERNEL_3X3S);
         return launch_c3s_gen((hipStream_t)stream, c, Cin, mt);
+    }
+    // -8: a 192- / 384-channel ReLU / linear layer on the streamed kernel with 32-channel slabs (pam_conv3x3_layout_small; same arithmetic;
+    // 16-channel slabs were measured too: no faster at 2-6 crops, slower from 9)
+    if (tile_cfg == -8) {
+        C3Args c;
+        int mt = 0, pmax = 0, ntw = 0;
+        if (!in || !w_img || !out || N <= 0 || KH != 3 || KW != 3 || stride != 1 || pad != 1 || in_cstride != Cin || relu_from != 0 || relu > 1 ||
+            !pam_conv3x3_layout_small(H, W, Cin, Cout) || !c3s_pick(H, W, Cin, Cout, c.TH, mt, pmax, ntw, 0) || (size_t)N * H * W * Cout * 2 >= (1ull << 31))
+            return PAM_E_ARG;
+        c.in = (const uint16_t*)in; c.wimg = (const uint16_t*)w_img; c.bias = bias; c.res = (const uint16_t*)residual; c.out = (uint16_t*)out;
+        c.N = N; c.H = H; c.W = W; c.Cout = Cout; c.relu = relu; c.inv_pw = 1.0f / (float)(W + 2);
+        c.tiles_y = (H + c.TH - 1) / c.TH;
+#ifdef PAM_DIAG
+        c.dbg = 0; c.stamps = nullptr;
+#endif
+        CONV_KIND(PAM_CONV_KERNEL_3X3S);
+        return launch_c3s((hipStream_t)stream, c, Cin, 2, mt, pmax);
     }
     const int c96_slab = tile_cfg == -5 ? 48 : 0;
     const bool force_streamed = tile_cfg == -3 || c96_slab != 0, no_streamed = tile_cfg == -4;

@@ -547,16 +547,19 @@ class HRNetPose(object):
         fsum:flags_on=1,fused_sums=1, end of round 5): up to 20 crops the fuse-layer sums carry their 1x1 products (k_fuse_sum, 18 launches
         fewer: 2-6 crops -3.0 ... -3.4 %, 8-16 crops -0.6 ... +0.7 %, 18 crops -1.3 %, 20 crops -1.7 %), above that they are separate launches
         (22 crops 0.0 %, 24 +0.5 %, 28 +1.6 %: the 1x1 launches hide beside the other branches' blocks and the sums are on the critical path).
+        Up to 12 crops the 192- / 384-channel 3x3 layers also run with 32-channel slabs (HipHRNet.slab32: a launch of a few crops is as long
+        as ONE workgroup; 2 crops -8 %, 4 -10 %, 6 -8 %, 9 -3 ... -6 %, 12 -2 %, 14 0 %, 16 +2 %).
         The 96-channel branch as streamed convolutions (round 4's choice for 8-12 crops under stream events) loses at every count now
         (+0.1 ... +5.6 %).  (Round 3 timed every configuration at the first replay of a crop count: 1.5 s per count, a choice decided by
         noise, and three dead captures per count that could never be destroyed, see _lib.new_graph.)"""
         name = type(self.hip).config_name
         if self.autotune:
-            name = 'fused48_fused96_fsum' if n <= self.fsum_max_crops else name
+            name = 'fused48_fused96_fsum_s32' if n <= self.s32_max_crops else ('fused48_fused96_fsum' if n <= self.fsum_max_crops else name)
         self.tuned[n] = {'choice': name}
         return name
 
-    fsum_max_crops = int(os.environ.get('PAM_FSUM_MAX', '20'))      # tuning hook of config_for's rule
+    fsum_max_crops = int(os.environ.get('PAM_FSUM_MAX', '20'))      # tuning hooks of config_for's rule
+    s32_max_crops = int(os.environ.get('PAM_S32_MAX', '12'))        # up to here the deep branches' 3x3 layers run with 32-channel slabs (-8 ... -10 % at 2-6 crops, -2 % at 12)
 
     def input_buffer(self, n, slot=0):
         """The (N,3,H,W) channels-last bf16 tensor the preprocessing kernel writes; the replay's own input when one

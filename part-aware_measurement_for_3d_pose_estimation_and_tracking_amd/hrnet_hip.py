@@ -361,6 +361,7 @@ class ConvEngine(object):
         return y
 
     pw64 = True                 # 64 -> 64 pointwise layers over >= 64 k pixels on the streaming kernel k_pw1 (ReLU or leaky)
+    slab32 = False              # round 5: the 192- / 384-channel 3x3 layers with 32-channel slabs (pam_conv3x3_layout_small): for forwards of a few crops
     gen_streamed = True         # Darknet 3x3 layers with Cin 128 / 256 / 512 on k_conv3x3s<.., GEN> (False: the classic k_conv3x3)
     tile_cfg = -1
     c96_slab = 0                # 96 -> 96 3x3 layers: 0 = k_conv3x3, 48 / 96 = the streamed kernel with slabs of that many output channels
@@ -420,9 +421,16 @@ class ConvEngine(object):
             if wimg is None:
                 wimg = op._images[('gen', bn)] = streamed_image(op._w_ohwi, bn, op._device)
             tile_cfg = -7
+        if (wimg is None and self.slab32 and tile_cfg == -1 and op.kh == 3 and op.kw == 3 and op.stride == 1 and op.pad == 1 and cin in (192, 384) and
+                in_cs == cin and relu_from == 0 and op._w_ohwi is not None and self.lib.pam_conv3x3_layout_small(h, w, cin, op.cout) > 0):
+            # forwards of a few crops: the deep branches' layers with 32-channel slabs (twice the workgroups, each half as long; bit-identical)
+            wimg = op._images.get(('s32', 32))
+            if wimg is None:
+                wimg = op._images[('s32', 32)] = streamed_image(op._w_ohwi, 32, op._device)
+            tile_cfg = -8
         if wimg is None:
             wimg = op.image(h, w, classic=(tile_cfg != -1), c96_slab=self.c96_slab) if (in_cs == cin and relu_from == 0) else None
-        if tile_cfg == -1 and wimg is not None and op._stem is None and tile_cfg != -7:
+        if tile_cfg == -1 and wimg is not None and op._stem is None:
             # automatic choice, but the layout of THIS image is stated: -3 streamed / -4 classic, -5 / -6 a 96 -> 96 layer streamed with
             # slabs of 48 / 96 output channels (the executor's choice, c96_slab)
             tile_cfg = ({48: -5, 96: -6}.get(getattr(op, 'last_c96', 0), -3)) if getattr(op, 'last_streamed', False) else -4
@@ -825,11 +833,14 @@ class HipHRNet(ConvEngine):
     # fused48_fused96 -8.2 %; 20 crops -3.3 / -7.3 %; 40 crops -4.1 / -8.9 %; 60 crops -5.7 / -11.2 %; 112 crops -1.7 / -7.6 %; 217 crops
     # +0.3 / -6.9 %.
     CONFIGS = {
-        'fused48_fused96': dict(block2=3, c96_slab=48, fused_sums=False),          # both fine branches: ONE fused-BasicBlock launch per block (csrc/pam_block2.hip)
-        'resident48_streamed96': dict(block2=1, c96_slab=48, fused_sums=False),    # 48-channel branch fused, 96-channel branch as two streamed convolutions per block
+        'fused48_fused96': dict(block2=3, c96_slab=48, fused_sums=False, slab32=False),          # both fine branches: ONE fused-BasicBlock launch per block (csrc/pam_block2.hip)
+        'resident48_streamed96': dict(block2=1, c96_slab=48, fused_sums=False, slab32=False),    # 48-channel branch fused, 96-channel branch as two streamed convolutions per block
         # round 5: up to 6 crops the fuse layers' 1x1 products run inside the sum launches (k_fuse_sum: 203 launches): a forward that small
         # is a chain of launch latencies (interleaved A/B: 2 crops -1.7 %, 4 -1.9 %, 6 -1.9 %, 8 -0.2 %, 12 +0.9 %, 20 +0.3 ... +1.5 %)
-        'fused48_fused96_fsum': dict(block2=3, c96_slab=48, fused_sums=True),
+        'fused48_fused96_fsum': dict(block2=3, c96_slab=48, fused_sums=True, slab32=False),
+        # round 5: up to 12 crops a launch of the deep branches is as long as ONE workgroup -> their 3x3 layers with 32-channel slabs (twice the
+        # workgroups, each half the MFMAs and weight bytes; bit-identical): 2 crops -8 %, 4 -10 %, 6 -8 %, 9 -3 ... -6 %, 12 -2 %, 14 0 %, 16 +2 %
+        'fused48_fused96_fsum_s32': dict(block2=3, c96_slab=48, fused_sums=True, slab32=True),
     }
 
     def apply_config(self, name):

@@ -147,6 +147,8 @@ def test_algorithmic_work_is_executor_independent_and_launch_counts_follow_the_c
     assert a["launches"] == 221 and b["launches"] == 253 and a['bytes_as_executed'] < b['bytes_as_executed']
     c = w['fused48_fused96_fsum']                                    # the small-forward configuration: the 1x1 products inside the sum launches
     assert c['launches'] == 203 and c['bytes'] == a['bytes'] and c['flops'] == a['flops'] and c['bytes_as_executed'] < a['bytes_as_executed']
+    d = w['fused48_fused96_fsum_s32']                                # + 32-channel slabs in the deep branches: the same launches and work
+    assert d['launches'] == 203 and d['bytes'] == c['bytes'] and d['flops'] == c['flops']
     assert a['bytes'] < a['bytes_as_executed']                       # the deep branches' block interiors are traffic only as executed
     assert hrnet.algorithmic_work(40)['bytes'] > 1.9 * a['bytes']    # activations scale with the crops, the weights do not
 

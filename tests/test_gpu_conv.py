@@ -237,3 +237,30 @@ def test_streamed_kernel_for_the_96_channel_branch(eng, shape, slab):
     torch.cuda.synchronize()
     err = (y.float() - ref).abs()
     assert bool((err <= 2.0 ** -7 * ref.abs() + 2e-2).all()), float(err.max())
+
+
+@pytest.mark.parametrize('shape', [(3, 24, 18, 192), (2, 12, 9, 384), (1, 48, 36, 192), (5, 6, 5, 384)])
+def test_deep_3x3_layers_with_32_channel_slabs_equal_the_64_channel_form(shape):
+    """tile_cfg -8 (HipHRNet.slab32, forwards of a few crops): the 192- / 384-channel 3x3 layers with 32-channel slabs -- twice the
+    workgroups, the same K order per output channel -> bit-identical to the 64-channel-slab launch, with and without the residual."""
+    from pam import _lib, hrnet_hip
+    n, h, w, c = shape
+    DEV = torch.device('cuda:0')
+    e = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); e.lib = _lib.load(); e.device = DEV; e.tile_cfg = -1
+    torch.manual_seed(3)
+    conv = nn.Conv2d(c, c, 3, 1, 1, bias=True)
+    op = hrnet_hip.PackedConv(conv, DEV)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((n, c, h, w), generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    r = torch.randn((n, c, h, w), generator=g).to(torch.bfloat16).to(DEV).contiguous(memory_format=torch.channels_last)
+    assert e.lib.pam_conv3x3_layout_small(h, w, c, c) == 32
+    for res, relu in ((None, True), (r, True), (None, False)):
+        e.slab32 = False
+        a = e.conv(op, x, res=res, relu=relu).clone()
+        e.slab32 = True
+        b = e.conv(op, x, res=res, relu=relu).clone()
+        e.slab32 = False
+        torch.cuda.synchronize()
+        assert e.lib.pam_conv_last_kernel() == 2 and ('s32', 32) in op._images
+        assert torch.equal(a, b)
+    assert e.lib.pam_conv3x3_layout_small(h, w, 96, 96) == 0

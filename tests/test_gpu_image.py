@@ -436,6 +436,8 @@ def test_replay_equals_eager_forward_in_every_configuration(n):
         outs[name] = ref.float()
     v = list(outs.values())
     assert float((v[0] - v[1]).norm() / v[0].norm()) < 1e-2
+    # the 32-channel-slab form of the deep branches' layers is the same arithmetic in the same order: bit-identical
+    assert torch.equal(outs['fused48_fused96_fsum'], outs['fused48_fused96_fsum_s32'])
 
 
 def test_bf16_stack_vs_fp32_at_the_256x192_resolution():
@@ -554,8 +556,10 @@ def test_configuration_follows_the_crop_count_and_stays_consistent():
     y2 = b.features(x).clone()
     y3 = b.features(x, slot=1).clone()
     torch.cuda.synchronize()
-    assert b.tuned[9]['choice'] == 'fused48_fused96_fsum' and a.tuned[9]['choice'] == hrnet_hip.HipHRNet.config_name == 'fused48_fused96'
-    assert b.config_for(4) == 'fused48_fused96_fsum' and b.config_for(20) == 'fused48_fused96_fsum' and b.config_for(21) == 'fused48_fused96'   # up to 20 crops: fused sums (round 5)
+    assert b.tuned[9]['choice'] == 'fused48_fused96_fsum_s32' and a.tuned[9]['choice'] == hrnet_hip.HipHRNet.config_name == 'fused48_fused96'
+    # up to 12 crops: fused sums + 32-channel slabs in the deep branches; up to 20: fused sums (round 5)
+    assert b.config_for(4) == b.config_for(12) == 'fused48_fused96_fsum_s32' and b.config_for(13) == b.config_for(20) == 'fused48_fused96_fsum'
+    assert b.config_for(21) == 'fused48_fused96'
     assert torch.equal(y1, y2) and torch.equal(y1, y3)
     assert float((y1.float() - ref).norm() / ref.norm()) < 1e-2
     x24 = b.input_buffer(24)

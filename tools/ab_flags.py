@@ -19,7 +19,7 @@ for v in args.variants:
     hip = net.hip
     for kv in [q for q in spec.split(',') if q]:
         k, _, val = kv.partition('=')
-        if k == 'fused_sums':                                                             # 1 = every output, else a bit mask over the outputs
+        if k in ('fused_sums', 'slab32'):                                                 # fused_sums: 1 = every output, else a bit mask over the outputs; slab32: 1 | 16
             setattr(hip, k, True if val == '1' else int(val))
         elif k in ('b96_tile', 'b48_tile', 'fs_cap', 'd48_tile'):                            # e.g. b96_tile=12x36
             setattr(hip, k, tuple(int(q) for q in val.split('x')))
