@@ -84,6 +84,9 @@ def test_block2_tile_choice_and_limits(eng):
     tr, tc = int(t[0]), int(t[1])
     assert 20 * -(-96 // tr) * -(-72 // tc) <= 256 and (tr + 4) * (tc + 4) <= 800       # one round of workgroups at 20 crops
     assert eng.lib.pam_basic_block2_tile(96, 20, 48, 36, t) == 0 and (int(t[0]) + 2) * (int(t[1]) + 4) <= 384      # 96 channels: weights streamed, 3 M tiles per wave
+    t20 = (int(t[0]), int(t[1]))
+    assert eng.lib.pam_basic_block2_tile(96, 4, 48, 36, t) == 0 and (int(t[0]), int(t[1])) == ((t20[0] + 1) // 2, t20[1])   # a few crops: items of half the size
+    assert eng.lib.pam_basic_block2_tile(96, 9, 48, 36, t) == 0 and (int(t[0]), int(t[1])) == t20
     x96 = torch.zeros((1, 96, 48, 36), dtype=torch.bfloat16, device=eng.device).contiguous(memory_format=torch.channels_last)
     w96 = torch.zeros(1024 + 2 * 27 * 96 * 64, dtype=torch.uint8, device=eng.device)
     rc = eng.lib.pam_basic_block2_nhwc_bf16(C.c_void_p(torch.cuda.current_stream(eng.device).cuda_stream), C.c_void_p(x96.data_ptr()), C.c_void_p(w96.data_ptr()),
