@@ -623,9 +623,11 @@ def main():
                        'tracker_stream_on_its_own_hw_queue': bool(pipe.track_overlaps) if overlap else None, 'hrnet_weights': pipe.net.weights if pipe.net else None,
                        'conv_backend': pipe.net.backend if pipe.net else None,
                        'conv_executor': ({str(n): t for n, t in pipe.net.tuned.items()} if pipe.net is not None and pipe.net.backend == 'hip' else None),
-                       'branch_sync': (('device-side flags (csrc/pam_sync.hip)' if all(pipe.net.flag_synced.values()) else 'stream events (flag check failed, flags lost the capture-time race -- a tracing profiler -- or PAM_FLAG_SYNC=0)')
+                       'branch_sync': ((lambda fs: 'device-side flags (csrc/pam_sync.hip)' if all(fs) else ('stream events (flags lost the capture-time race -- a tracing '
+                                       'profiler? -- or PAM_FLAG_SYNC=0)' if not any(fs) else 'device-side flags for crop counts %s, stream events for %s (capture-time race)' % (
+                                       sorted({k[0] for k, v in pipe.net.flag_synced.items() if v}), sorted({k[0] for k, v in pipe.net.flag_synced.items() if not v}))))(list(pipe.net.flag_synced.values()))
                                        if pipe.net is not None and pipe.net.flag_synced else None),
-                       'branch_sync_race_ms': (pipe.net.flag_timing if pipe.net is not None else None),
+                       'branch_sync_race_ms': ({str(k): v for k, v in pipe.net.flag_timing.items()} if pipe.net is not None else None),
                        'exchange': ('one all-gather per frame (%s)' % ('pam_allgather_keypoints: RCCL called inside the C ABI' if pipe.comm else 'torch.distributed ' + backend)) if world > 1 else 'none',
                        'devices': '%d ranks on ONE device (no multi-GPU box: functional check only)' % world if single_dev and world > 1 else '%d' % world},
             'roofline': {'kernel': 'HRNet-W48 conv stack: k_stem_fused / k_bneck / k_bblock2_48 / k_bblock2_96 / k_conv3x3[s] / k_down48 / k_down_s / k_conv_gs / k_fuse_sum / k_upsample_add '

@@ -326,7 +326,8 @@ class HRNetPose(object):
         self.hip.flag_host_err = self._flag_host
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > torch.cuda.device_count():
             self._flag_sync_failed = True                 # ranks share a device: stream events (see FramePipeline)
-        self.flag_timing = None      # the race of the first flagged capture against stream events: dict(crops, flags_ms, events_ms)
+        self.flag_timing = {}        # crop count -> the race of its first flagged capture against stream events: dict(flags_ms, events_ms, mode, kept)
+        self.flag_race = 'serial'    # how that race is timed: 'serial' (one replay at a time: predict()'s use), 'throughput' (back to back: FramePipeline), None = no race
         self._dead_graphs = []       # captures that lost that race or failed the flag check (never destroyed: _lib.new_graph)
         self.captures = 0            # hipGraph captures made so far (a capture inside a frame is a stall of hundreds of ms: warm())
         # predict() pads a batch to the next multiple of graph_bucket crops (repeating its last box; the padded rows are not
@@ -402,26 +403,31 @@ class HRNetPose(object):
                     for _ in range(2):
                         self._forward(static_in, kind)
                 torch.cuda.current_stream(self.device).wait_stream(s)
-                graph, static_out, flags = self._capture(static_in, kind, slot, self._flag_sync_ok())
+                raced = self.flag_timing.get(n)
+                graph, static_out, flags = self._capture(static_in, kind, slot, self._flag_sync_ok() and (raced is None or raced['kept']))
                 if flags is not None:
                     # the flagged replay once, then its error word: a gate that timed out (two branch chains on one in-order hardware queue,
                     # a profiler that serialises kernels) -> this object goes back to stream events, for this and every later capture
                     # (the flagged capture stays alive: captured graphs are never destroyed, _lib.new_graph)
                     graph.replay()
                     torch.cuda.synchronize(self.device)
-                    keep = int(flags[0].item()) == 0
+                    ok = int(flags[0].item()) == 0
                     self._flag_host_np[0] = 0                                             # (a time-out of THIS replay is dealt with here)
-                    other_form = None
-                    if keep and self.flag_timing is None:
-                        # the FIRST flagged capture of this object is raced against the same forward ordered by stream events: under
-                        # rocprofv3's kernel tracing the gates wait ~1 ms each (measured: 79 instead of 410 frames/s) without ever
-                        # timing out; flags stay unless they lose by more than 10 % (they win by 1-6 % on an untraced device)
+                    keep, other_form = ok, None
+                    if ok and raced is None and self.flag_race:
+                        # the first flagged capture of every crop count is raced against the same forward ordered by stream events, timed the
+                        # way this object is used (flag_race): 'throughput' = replays back to back (FramePipeline: the host runs a frame
+                        # ahead; flags win by 1-6 %), 'serial' = one replay at a time (the synchronous drop-in surface: the runtime enqueues
+                        # a flagged graph chain by chain, so a new branch's first kernel is enqueued ~200 us after the caller stream's, which
+                        # only back-to-back replays hide -- small forwards lose more to that than the joins cost).  Under rocprofv3's kernel
+                        # tracing the gates wait ~1 ms each (79 instead of 410 frames/s) without ever timing out: flags lose every race.
                         other_form = self._capture(static_in, kind, slot, False)
-                        t_flags, t_events = self._replay_ms(graph), self._replay_ms(other_form[0])
-                        self.flag_timing = dict(crops=n, flags_ms=t_flags, events_ms=t_events)
-                        keep = t_flags <= 1.10 * t_events
+                        t_flags, t_events = self._replay_ms(graph, self.flag_race), self._replay_ms(other_form[0], self.flag_race)
+                        keep = t_flags <= t_events
+                        self.flag_timing[n] = dict(flags_ms=t_flags, events_ms=t_events, mode=self.flag_race, kept=keep)
                     if not keep:
-                        self._flag_sync_failed = True
+                        if not ok:
+                            self._flag_sync_failed = True
                         dead = (graph, static_out, flags)
                         graph, static_out, flags = other_form if other_form is not None else self._capture(static_in, kind, slot, False)
                     else:
@@ -441,8 +447,17 @@ class HRNetPose(object):
         graph.replay()
         return static_out
 
-    def _replay_ms(self, graph, reps=3):
-        """Shortest of `reps` replays of a captured forward, ms (events on the caller's stream)."""
+    def _replay_ms(self, graph, mode='serial', reps=4):
+        """ms per replay of a captured forward (events on the caller's stream): 'serial' = the shortest of `reps` replays issued one at a
+        time, 'throughput' = `reps` replays issued back to back."""
+        if mode == 'throughput':
+            graph.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                graph.replay()
+            e1.record(); e1.synchronize()
+            return e0.elapsed_time(e1) / reps
         best = float('inf')
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -73,6 +73,8 @@ class FramePipeline(object):
         # each other's queues, and so can the replays of several ranks that share one device (more ranks than devices: one-device tests)
         if self.net is not None and (self.pose_streams is not None or world > torch.cuda.device_count()):
             self.net.disable_flag_sync()
+        if self.net is not None:
+            self.net.flag_race = 'throughput'        # the pipeline keeps the host a frame ahead of the device: time the flag race that way
         self.bucketed, self.warmed = bool(prewarm), None
         if prewarm and self.net is not None:
             most = (self.C if shard == 'crops' else len(self.mine)) * max_dets

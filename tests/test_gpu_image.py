@@ -1,5 +1,7 @@
 """GPU: the image-side HIP kernels (crop/resize/normalise, heat-map decode) against plain torch float32 restatements,
 the bf16 conv stack against its own fp32 form, and the on-device pipeline decode -> tracker against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -616,35 +618,69 @@ def test_preprocess_antialias_matches_the_pil_formula(net):
     assert float(x[:, 3:].float().abs().max()) == 0.0
 
 
+_FLAG_CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+import torch
+import pam
+from pam import hrnet, _lib
+a = hrnet.HRNetPose(48, 17, None, use_graph=False)
+b = hrnet.HRNetPose(48, 17, None, use_graph=True)
+b.flag_race = None                                  # no race against stream events: this object keeps its flagged captures
+x = a.input_buffer(5)
+x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(x.device).to(x.dtype)); x[:, 3:] = 0
+ref = a.features(x).clone()
+for _ in range(10):
+    y = b.features(x)
+torch.cuda.synchronize()
+assert b.flag_synced[(5, 'features', 0)] is True, (b.flag_synced, getattr(b, '_flag_sync_failed', None))
+assert torch.equal(ref, y)
+assert b.captures == 1 and len(b._dead_graphs) == 0 and int(b._flag_host_np[0]) == 0
+# the first flagged capture of a crop count is raced against stream events, timed the way the object is used, and the faster form
+# stays (one discarded capture per crop count, not counted as a replay of the cache); a second slot of the count follows the verdict
+for mode in ('serial', 'throughput'):
+    d = hrnet.HRNetPose(48, 17, None, use_graph=True)
+    d.flag_race = mode
+    yd = d.features(x).clone(); torch.cuda.synchronize()
+    t = d.flag_timing[5]
+    assert t['mode'] == mode and t['kept'] == (t['flags_ms'] <= t['events_ms']) == d.flag_synced[(5, 'features', 0)]
+    assert d.captures == 1 and len(d._dead_graphs) == 1 and torch.equal(ref, yd)
+    y1 = d.features(x, slot=1).clone(); torch.cuda.synchronize()
+    assert d.flag_synced[(5, 'features', 1)] == t['kept'] and len(d._dead_graphs) == 1 and torch.equal(ref, y1)
+# a time-out in a LATER replay reaches the host through the pinned word: the next call raises and the object falls back
+b._flag_host_np[0] = 1
+try:
+    b.features(x)
+    raise SystemExit('no PamError')
+except _lib.PamError as e:
+    assert 'gate' in str(e)
+y4 = b.features(x).clone(); torch.cuda.synchronize()
+assert b.flag_synced[(5, 'features', 0)] is False and torch.equal(ref, y4)
+print('FLAGS-OK')
+"""
+
+
 def test_replays_order_their_branch_streams_by_device_flags_and_fall_back_when_a_gate_times_out():
     """Captured forwards meet at the module ends through counters in device memory (csrc/pam_sync.hip) instead of stream events: same
-    features as the eager forward (which uses stream events), error word zero over many replays; a capture whose first replay raises the
-    error word (here: a time-out of 1 us, which every gate exceeds) is replaced by one with stream events, with the same result."""
+    features as the eager forward (which uses stream events), error word zero over many replays; the capture-time race; the host word.
+    In a FRESH process: whether the chains of a graph get hardware queues of their own depends on how many streams the process has made
+    (a pytest session has made dozens; a flagged capture whose check times out there falls back to stream events, which is the second
+    half of this test).  Then, in this process: a capture whose first replay raises the error word (here: a time-out of 1 us, which every
+    gate exceeds) is replaced by one with stream events, with the same result."""
+    import subprocess
+    import sys
     from pam import hrnet
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', _FLAG_CHILD % root], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and 'FLAGS-OK' in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
     a = hrnet.HRNetPose(48, 17, None, use_graph=False)
-    b = hrnet.HRNetPose(48, 17, None, use_graph=True)
     x = a.input_buffer(5)
     x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(x.device).to(x.dtype)); x[:, 3:] = 0
     ref = a.features(x).clone()
-    for _ in range(10):
-        y = b.features(x)
-    torch.cuda.synchronize()
-    assert b.flag_synced[(5, 'features', 0)] is True and torch.equal(ref, y)
-    # the first flagged capture was raced against stream events and kept (one discarded capture, not counted as a replay of the cache)
-    assert b.captures == 1 and len(b._dead_graphs) == 1 and b.flag_timing['flags_ms'] <= 1.10 * b.flag_timing['events_ms']
-    b.features(a.input_buffer(8)); torch.cuda.synchronize()
-    assert b.captures == 2 and len(b._dead_graphs) == 1 and b.flag_synced[(8, 'features', 0)] is True
     c = hrnet.HRNetPose(48, 17, None, use_graph=True)
     c.hip.flag_max_us = 1
     y2 = c.features(x).clone()
     torch.cuda.synchronize()
     assert c.flag_synced[(5, 'features', 0)] is False and c.captures == 1 and len(c._dead_graphs) == 1 and torch.equal(ref, y2)
-    assert c._flag_sync_ok() is False                   # and the process stays with stream events
+    assert c._flag_sync_ok() is False                   # and the object stays with stream events
     assert int(c._flag_host_np[0]) == 0                 # the time-outs of the checked replay were dealt with there
-    # a time-out in a LATER replay reaches the host through the pinned word: the next call raises and the object falls back
-    from pam import _lib
-    b._flag_host_np[0] = 1
-    with pytest.raises(_lib.PamError, match='gate'):
-        b.features(x)
-    y4 = b.features(x).clone(); torch.cuda.synchronize()
-    assert b.flag_synced[(5, 'features', 0)] is False and torch.equal(ref, y4)
