@@ -819,15 +819,19 @@ def surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, K
         dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbls[t], batch_size=max(20, len(sum(pbls[t], []))))
         dump.device_det.copy_(det_dev[t]); dump.poses_host = det_host[t]      # synthetic keypoints instead of the random net's
         return model.PersonTrack_Project3DPose(t, pbls[t], dump, 'SVD')
-    for t in range(W):
-        one(t)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        r = one(t)
-        emitted += len(r[5])
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    race_mode, pipe.net.flag_race = pipe.net.flag_race, 'serial'      # this loop needs each frame's result on the host before the next: the
+    try:                                                               # network's replays pick the form that is faster one at a time
+        for t in range(W):
+            one(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(W, W + K):
+            r = one(t)
+            emitted += len(r[5])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    finally:
+        pipe.net.flag_race = race_mode
     return {'value': K / el, 'unit': 'frames/s', 'ms_per_step': el / K * 1e3, 'steps': K, 'emitted_poses': emitted,
             'what': 'ivclabpose.PersonPoseDetect + PersonTrack_Project3DPose per frame (host lists out of predict, 9-tuple out of the tracker; '
                     'keypoints handed over on the device)'}

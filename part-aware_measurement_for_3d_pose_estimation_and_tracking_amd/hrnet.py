@@ -326,8 +326,9 @@ class HRNetPose(object):
         self.hip.flag_host_err = self._flag_host
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > torch.cuda.device_count():
             self._flag_sync_failed = True                 # ranks share a device: stream events (see FramePipeline)
-        self.flag_timing = {}        # crop count -> the race of its first flagged capture against stream events: dict(flags_ms, events_ms, mode, kept)
-        self.flag_race = 'serial'    # how that race is timed: 'serial' (one replay at a time: predict()'s use), 'throughput' (back to back: FramePipeline), None = no race
+        self.flag_timing = {}        # crop count -> the race of its first flagged capture against stream events: dict(ms={mode: (flags, events)}, kept={mode: bool})
+        self._alt = {}               # (crops, kind, slot) -> {mode: (graph, static_in, static_out)} when both forms exist
+        self.flag_race = 'serial'    # which timing of that race picks a replay's form: 'serial' (one replay at a time: predict()'s use), 'throughput' (back to back: FramePipeline); None = no race, flags stay
         self._dead_graphs = []       # captures that lost that race or failed the flag check (never destroyed: _lib.new_graph)
         self.captures = 0            # hipGraph captures made so far (a capture inside a frame is a stall of hundreds of ms: warm())
         # predict() pads a batch to the next multiple of graph_bucket crops (repeating its last box; the padded rows are not
@@ -404,7 +405,9 @@ class HRNetPose(object):
                         self._forward(static_in, kind)
                 torch.cuda.current_stream(self.device).wait_stream(s)
                 raced = self.flag_timing.get(n)
-                graph, static_out, flags = self._capture(static_in, kind, slot, self._flag_sync_ok() and (raced is None or raced['kept']))
+                want_flags = self._flag_sync_ok() and (raced is None or raced['kept']['serial'] or raced['kept']['throughput'])
+                graph, static_out, flags = self._capture(static_in, kind, slot, want_flags)
+                alt = None
                 if flags is not None:
                     # the flagged replay once, then its error word: a gate that timed out (two branch chains on one in-order hardware queue,
                     # a profiler that serialises kernels) -> this object goes back to stream events, for this and every later capture
@@ -413,34 +416,33 @@ class HRNetPose(object):
                     torch.cuda.synchronize(self.device)
                     ok = int(flags[0].item()) == 0
                     self._flag_host_np[0] = 0                                             # (a time-out of THIS replay is dealt with here)
-                    keep, other_form = ok, None
-                    if ok and raced is None and self.flag_race:
-                        # the first flagged capture of every crop count is raced against the same forward ordered by stream events, timed the
-                        # way this object is used (flag_race): 'throughput' = replays back to back (FramePipeline: the host runs a frame
-                        # ahead; flags win by 1-6 %), 'serial' = one replay at a time (the synchronous drop-in surface: the runtime enqueues
-                        # a flagged graph chain by chain, so a new branch's first kernel is enqueued ~200 us after the caller stream's, which
-                        # only back-to-back replays hide -- small forwards lose more to that than the joins cost).  Under rocprofv3's kernel
-                        # tracing the gates wait ~1 ms each (79 instead of 410 frames/s) without ever timing out: flags lose every race.
-                        other_form = self._capture(static_in, kind, slot, False)
-                        t_flags, t_events = self._replay_ms(graph, self.flag_race), self._replay_ms(other_form[0], self.flag_race)
-                        keep = t_flags <= t_events
-                        self.flag_timing[n] = dict(flags_ms=t_flags, events_ms=t_events, mode=self.flag_race, kept=keep)
-                    if not keep:
-                        if not ok:
-                            self._flag_sync_failed = True
-                        dead = (graph, static_out, flags)
-                        graph, static_out, flags = other_form if other_form is not None else self._capture(static_in, kind, slot, False)
-                    else:
-                        dead = other_form
-                    if dead is not None:
-                        self._dead_graphs.append(dead)
+                    if not ok:
+                        self._flag_sync_failed = True
+                        self._dead_graphs.append((graph, static_out, flags))
+                        graph, static_out, flags = self._capture(static_in, kind, slot, False)
+                    elif self.flag_race:
+                        # every flagged capture has the same forward ordered by stream events beside it, and both are timed both ways: 'throughput'
+                        # = replays back to back (FramePipeline: the host runs a frame ahead; flags win by 1-6 %), 'serial' = one replay at a
+                        # time (the synchronous drop-in surface: the runtime enqueues a flagged graph chain by chain, so a new branch's first
+                        # kernel is enqueued ~200 us after the caller stream's, which only back-to-back replays hide -- small forwards lose
+                        # more to that than the joins cost).  A replay uses the form that is faster in the object's CURRENT mode (flag_race).
+                        # Under rocprofv3's kernel tracing the gates wait ~1 ms each without ever timing out: flags lose every race.
+                        ev_graph, ev_out, _ = self._capture(static_in, kind, slot, False)
+                        if raced is None:
+                            t = {m: (self._replay_ms(graph, m), self._replay_ms(ev_graph, m)) for m in ('serial', 'throughput')}
+                            raced = self.flag_timing[n] = dict(ms=t, kept={m: t[m][0] <= t[m][1] for m in t})
+                        alt = {'flags': (graph, static_in, static_out), 'events': (ev_graph, static_in, ev_out)}
                 self.captures += 1
             self.hip.arena = None
             g = (graph, static_in, static_out)
             self._graphs[(n, kind, slot)] = g
-            self.flag_synced[(n, kind, slot)] = flags is not None
+            self._alt[(n, kind, slot)] = alt
+            self.flag_synced[(n, kind, slot)] = flags is not None if alt is None else bool(raced['kept'][self.flag_race])
         if self._flag_host_np[0] != 0:
             self._flag_timeout()
+        alt = self._alt.get((n, kind, slot))
+        if alt is not None:                                # two forms of this forward: the one that is faster the way this object is used now
+            g = alt['flags' if self.flag_timing[n]['kept'][self.flag_race or 'throughput'] else 'events']
         graph, static_in, static_out = g
         if static_in.data_ptr() != x.data_ptr():
             static_in.copy_(x)
@@ -470,9 +472,13 @@ class HRNetPose(object):
         destroyed) and are re-captured at their next use.  For callers that keep two forwards in flight at the same time: the gates
         of two flagged replays can block each other's hardware queues (FramePipeline(pose_streams=2) calls this)."""
         self._flag_sync_failed = True
-        for key in [k for k, on in self.flag_synced.items() if on]:
-            self._dead_graphs.append(self._graphs.pop(key))
-            self.flag_synced.pop(key)
+        for key in list(self.flag_synced):
+            alt = self._alt.pop(key, None)
+            if alt is not None:                            # the stream-event form of this forward exists already
+                self._dead_graphs.append(alt['flags']); self._graphs[key] = alt['events']; self.flag_synced[key] = False
+            elif self.flag_synced[key]:
+                self._dead_graphs.append(self._graphs.pop(key))
+                self.flag_synced.pop(key)
 
     def _flag_timeout(self):
         """A gate of an earlier replay gave up (pam_flag_gate's host word): the forwards replayed since the last check may have read
