@@ -387,6 +387,7 @@ class HRNetPose(object):
 
     def _run(self, x, kind, slot=0):
         n = x.shape[0]
+        assert self.flag_race in (None, 'serial', 'throughput'), self.flag_race
         if not self.use_graph:
             with torch.no_grad():
                 return self._forward(x, kind)
