@@ -178,3 +178,22 @@ def test_conv64_image_follows_the_layout_pam_h_documents():
     rows = torch.arange(64)
     chs = 32 * ((rows // 16) >> 1) + 8 * ((rows % 16) >> 2) + 4 * ((rows // 16) & 1) + (rows % 16 & 3)
     assert sorted(chs.tolist()) == list(range(64))
+
+
+def test_executor_rule_by_crop_count_and_configurations_set_the_same_switches():
+    """HRNetPose.config_for (host logic): up to 12 crops fused sums + 32-channel slabs in the deep branches, up to 20 fused sums, above the
+    1x1 products as launches of their own; without autotune one configuration for every count.  Every configuration sets the same
+    switches, so going from one to another leaves nothing behind."""
+    from pam import hrnet, hrnet_hip
+    net = hrnet.HRNetPose.__new__(hrnet.HRNetPose)
+    net.hip = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet); net.autotune = True; net.tuned = {}
+    got = [net.config_for(n) for n in (1, 12, 13, 20, 21, 217)]
+    assert got == ['fused48_fused96_fsum_s32'] * 2 + ['fused48_fused96_fsum'] * 2 + ['fused48_fused96'] * 2
+    assert net.tuned[20] == {'choice': 'fused48_fused96_fsum'}
+    net.autotune = False
+    assert {net.config_for(n) for n in (1, 12, 20, 217)} == {'fused48_fused96'}
+    keys = {frozenset(c) for c in hrnet_hip.HipHRNet.CONFIGS.values()}
+    assert len(keys) == 1 and {'block2', 'fused_sums', 'slab32'} <= set(next(iter(keys)))
+    h = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
+    h.apply_config('fused48_fused96_fsum_s32'); assert h.slab32 is True and h.fused_sums is True
+    h.apply_config('fused48_fused96'); assert h.slab32 is False and h.fused_sums is False and h.config_name == 'fused48_fused96'
