@@ -197,3 +197,21 @@ def test_executor_rule_by_crop_count_and_configurations_set_the_same_switches():
     h = hrnet_hip.HipHRNet.__new__(hrnet_hip.HipHRNet)
     h.apply_config('fused48_fused96_fsum_s32'); assert h.slab32 is True and h.fused_sums is True
     h.apply_config('fused48_fused96'); assert h.slab32 is False and h.fused_sums is False and h.config_name == 'fused48_fused96'
+
+
+def test_disable_flag_sync_swaps_to_the_stream_event_forms():
+    """HRNetPose.disable_flag_sync (host logic; FramePipeline(pose_streams=2), ranks sharing a device, a gate time-out): a forward that has
+    both forms keeps its stream-event capture, a flagged-only capture leaves the cache (re-captured at its next use), captures that
+    already use stream events stay; nothing is destroyed."""
+    from pam import hrnet
+    net = hrnet.HRNetPose.__new__(hrnet.HRNetPose)
+    k1, k2, k3 = (20, 'features', 0), (8, 'features', 0), (4, 'features', 0)
+    net._graphs = {k1: ('F1',), k2: ('F2',), k3: ('E3',)}
+    net._alt = {k1: {'flags': ('F1',), 'events': ('E1',)}, k2: None, k3: None}
+    net.flag_synced = {k1: True, k2: True, k3: False}
+    net.flag_timing = {20: dict(kept={'serial': True, 'throughput': True})}
+    net._dead_graphs = []
+    net.disable_flag_sync()
+    assert net._graphs == {k1: ('E1',), k3: ('E3',)} and net.flag_synced == {k1: False, k3: False}
+    assert net._dead_graphs == [('F1',), ('F2',)] and net._flag_sync_failed is True and net._alt.get(k1) is None
+    assert net._flag_sync_ok.__func__ is hrnet.HRNetPose._flag_sync_ok
