@@ -67,7 +67,9 @@ typedef struct PamOutLayout {
     /* int32 section: header then per-track blocks (list order = the reference's self.tracks order) */
     int32_t hdr_words;      /* [0]=n_tracks [1]=status word: bits 0-15 = status bits OF THIS FRAME: 1 = out of track slots, 2 = out of
                              * hypothesis slots, 4 = an assignment problem was infeasible, 8 = a device-side detection count outside
-                             * [0, max_dets] was clamped (pam_frame_dev); bits 16-31 = the same bits OR-ed over EVERY frame since
+                             * [0, max_dets] was clamped (pam_frame_dev), 16 = the frame's input was VOID (pam_set_input_guard): the frame was
+                             * not applied -- state untouched, no tracks in the record, [3] = first frame of this run of void frames (never
+                             * sticky); bits 16-31 = bits 1-8 OR-ed over EVERY frame since
                              * pam_create / pam_reset (sticky: a host that decodes only the last record of a run still sees them)
                              * [2]=frame_id [3]=n_hyp (debug) */
     int32_t trk_words;      /* words per track block */
@@ -118,6 +120,13 @@ int pam_frame_dev(PamHandle* h, void* stream, int frame_id, const int32_t* dev_n
 int pam_frame_dev_views(PamHandle* h, void* stream, int frame_id, const double* dev_records, const int32_t* dev_view_row);
 int pam_fetch(PamHandle* h, void* stream, int32_t* host_out_i, double* host_out_d);
 int pam_sync(PamHandle* h, void* stream);
+/* Input guard of the frame step (round 6).  The reference's PersonPoseDetect returns host lists before PersonTrack_Project3DPose runs
+ * (/root/reference/src/ivclabpose.py:208-287): a frame can never be tracked on keypoints their producer disowns.  Here the tracker consumes
+ * the decode on the device, so the producer's verdict has to be readable there: while *dev_word != 0 (a device int32 the producer raises:
+ * pam_flag_gate's dev_void; for view-sharded input also the second double of any record's count row) pam_frame* does NOT apply the frame --
+ * the state stays as it is and the record carries status bit 16.  The host re-submits from record word [3] once it has cleared the word.
+ * dev_word = NULL removes the guard. */
+int pam_set_input_guard(PamHandle* h, const int32_t* dev_word);
 
 /* ---- per-operator entry points (parity tests; host buffers, synchronous) -----------------------------------*/
 /* Camera.projectPoints_parallel, ivclabpose.py:91-98: n poses (17x3) -> (17x2) in (y, x) */
@@ -371,12 +380,14 @@ int pam_fuse_sum_nhwc_bf16(void* stream, const void* base, int n_plain, const vo
 /* ---- round 5: device-side ordering of the forward's branch streams (csrc/pam_sync.hip; the module-end exchange of hrnet.py:64-100 inside
  * the absent HRNet backend, /root/reference/src/ivclabpose.py:210).  pam_flag_signal: one agent-scope atomic add on *dev_counter behind
  * everything already queued on `stream`.  pam_flag_gate: [arrive != 0: first the same add, then] `stream` goes on once *dev_counter >= target (one wave polls; the launches that
- * follow on the stream see what the signalling streams' earlier kernels wrote); after max_us microseconds it sets *dev_err = 1 and lets
- * the stream go on regardless -- the caller checks dev_err (and host_err, when given: a word of pinned host memory that receives 1 at a
- * time-out, readable by the host without touching the device; NULL = none).  Counters are zeroed by the caller in front of the first
- * signal.  Flagged forwards of one process must not be in flight at the same time (their gates can block each other's queues). */
+ * follow on the stream see what the signalling streams' earlier kernels wrote); after *dev_max_us microseconds (a device word read when
+ * the gate starts: the bound of a captured gate can be changed between replays) it sets *dev_err = 1 and lets the stream go on
+ * regardless -- the caller checks dev_err (and host_err, when given: a word of pinned host memory that receives 1 at a time-out, readable
+ * by the host without touching the device; and dev_void, when given: a device word that receives 1, for consumers of the forward's
+ * results on the device -- pam_set_input_guard; NULL = none).  Counters are zeroed by the caller in front of the first signal.  Flagged forwards of one process must not be in flight at the same time (their gates can block each other's queues). */
 int pam_flag_signal(void* stream, int32_t* dev_counter);
-int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, int max_us, int arrive, int32_t* host_err);
+int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, const uint32_t* dev_max_us, int arrive, int32_t* host_err,
+                  int32_t* dev_void);
 
 /* ---- row e: the path's one exchange, in the C ABI (the reference has no distributed code -- it hands every visible GPU
  * to HRNet, /root/reference/src/ivclabpose.py:107-111,131-132).  One process per GPU; camera views are partitioned over the ranks; before

@@ -89,7 +89,8 @@ _SIGS = {
     'pam_conv3x3s2_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P] + [_I] * 7),
     'pam_fuse_sum_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 8),
     'pam_flag_signal': (_I, [_P, _P]),
-    'pam_flag_gate': (_I, [_P, _P, _I, _P, _I, _I, _P]),
+    'pam_flag_gate': (_I, [_P, _P, _I, _P, _P, _I, _P, _P]),
+    'pam_set_input_guard': (_I, [_P, _P]),
     'pam_comm_unique_id': (_I, [_P]),
     'pam_comm_init': (_I, [C.POINTER(_P), _I, _I, _P, _I]),
     'pam_comm_destroy': (_I, [_P]),
@@ -167,6 +168,20 @@ def new_graph():
 
 class PamError(RuntimeError):
     pass
+
+
+# status bits of the frame record (include/pam.h, PamOutLayout.hdr_words)
+ST_TRACK_OVERFLOW, ST_HYP_OVERFLOW, ST_LSAP_INFEASIBLE, ST_NDET_CLAMPED, ST_INPUT_VOID = 1, 2, 4, 8, 16
+
+
+class FrameVoid(PamError):
+    """The frame step skipped frames because the producer of their keypoints declared them void (a device-side gate of the captured
+    HRNet forward timed out; pam_set_input_guard): the tracker state is that of the last applied frame.  ``first`` = the first skipped
+    frame -- re-submit from there (the pose network orders its branch streams by stream events by now)."""
+
+    def __init__(self, first, last):
+        PamError.__init__(self, 'frames %d..%d were not applied: their keypoints were void (gate time-out); re-submit from frame %d' % (first, last, first))
+        self.first, self.last = int(first), int(last)
 
 
 def gaussian_taps(sigma, truncate=4.0):
@@ -274,6 +289,11 @@ class Handle(object):
         self._chk(self.lib.pam_frame_dev_views(self._h, C.c_void_p(stream), int(frame_id), C.c_void_p(dev_records_ptr),
                                                C.c_void_p(dev_view_row_ptr)))
 
+    def set_input_guard(self, dev_word_ptr):
+        """While the device int32 at dev_word_ptr is non-zero the frame step skips its frame (record status ``ST_INPUT_VOID``, state
+        untouched): the word is raised by the producer of the keypoints (HRNetPose.void_word).  None / 0 removes the guard."""
+        self._chk(self.lib.pam_set_input_guard(self._h, C.c_void_p(dev_word_ptr or None)))
+
     def fetch(self, stream, out_i=None, out_d=None):
         out_i = self.out_i if out_i is None else out_i
         out_d = self.out_d if out_d is None else out_d
@@ -306,6 +326,7 @@ class Handle(object):
         # status word: bits 0-15 = this frame's bits, bits 16-31 = OR of every frame's bits since create / reset (include/pam.h)
         w = int(oi[1]) & 0xffffffff
         return dict(n_tracks=n, status=w & 0xffff, status_sticky=(w >> 16) & 0xffff, frame_id=int(oi[2]), n_hyp=int(oi[3]),
+                    first_void=int(oi[3]) if (w & ST_INPUT_VOID) else None,
                     clocks=od[:4].copy(), clocks_all=od[:L.dbl_hdr_words].copy(), tracks=tracks)
 
     # ---- per-operator entry points (parity tests) -------------------------------------------------------------------

@@ -24,13 +24,14 @@ __global__ __launch_bounds__(64) void k_flag_signal(int* counter) {
     }
 }
 
-__global__ __launch_bounds__(64) void k_flag_gate(int* counter, int target, int* err, unsigned max_us, int arrive, int* host_err) {
+__global__ __launch_bounds__(64) void k_flag_gate(int* counter, int target, int* err, const unsigned* max_us_p, int arrive, int* host_err, int* dev_void) {
     if (threadIdx.x == 0) {
         if (arrive) {                                     // arrive-and-wait: this stream's own contribution, then everybody else's
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        const unsigned max_us = *max_us_p;                                      // a device word: the host can change the bound of captured gates
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(16);
@@ -38,6 +39,8 @@ __global__ __launch_bounds__(64) void k_flag_gate(int* counter, int target, int*
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)max_us * 100ull) {
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the consumers of this forward's keypoints on the DEVICE (the frame kernel: pam_set_input_guard) must not use them either
+                if (dev_void) __hip_atomic_store(dev_void, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (host_err) __hip_atomic_store(host_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
@@ -51,8 +54,10 @@ extern "C" int pam_flag_signal(void* stream, int32_t* dev_counter) {
     hipLaunchKernelGGL(k_flag_signal, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counter);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
-extern "C" int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, int max_us, int arrive, int32_t* host_err) {
-    if (!dev_counter || !dev_err || target < 1 || max_us < 1) return PAM_E_ARG;
-    hipLaunchKernelGGL(k_flag_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counter, target, dev_err, (unsigned)max_us, arrive ? 1 : 0, host_err);
+extern "C" int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, const uint32_t* dev_max_us, int arrive, int32_t* host_err,
+                             int32_t* dev_void) {
+    if (!dev_counter || !dev_err || target < 1 || !dev_max_us) return PAM_E_ARG;
+    hipLaunchKernelGGL(k_flag_gate, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counter, target, dev_err, (const unsigned*)dev_max_us, arrive ? 1 : 0, host_err,
+                       dev_void);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }

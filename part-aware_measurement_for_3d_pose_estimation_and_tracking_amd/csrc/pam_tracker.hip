@@ -19,6 +19,8 @@ using namespace pam;
 #define ST_HYP_OVERFLOW 2
 #define ST_LSAP_INFEASIBLE 4
 #define ST_NDET_CLAMPED 8       /* a per-view detection count outside [0, max_dets] was clamped (pam_frame_dev takes device counts unchecked) */
+#define ST_INPUT_VOID 16        /* the producer of this frame's keypoints declared them void (pam_set_input_guard / the records' void flag): the
+                                   frame was NOT applied -- state untouched, record without tracks, out_i[3] = first void frame of the run of void frames */
 #define BLOCK 256
 
 struct Dims { int C, MAXP, MAXT, HCAP, MAXH, S, N1, N2; };
@@ -150,6 +152,7 @@ struct FrameArgs {
     PamOutLayout ol;
     int frame_id;
     int hot_in_lds;
+    const int* guard;      // pam_set_input_guard: a device word the producer of the keypoints raises when they are void (pam_flag_gate's dev_void)
 };
 
 __device__ const int g_zeroT[PAM_MAX_VIEWS] = {0};
@@ -171,6 +174,27 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
     extern __shared__ __attribute__((aligned(16))) char hot_lds[];
     char* const st_glob = A.state + (size_t)sidx * A.state_stride;
     const size_t st_ints = state_int_bytes(d);
+    // ---- input guard: keypoints whose producer gave up (a device-side gate of the captured HRNet forward timed out, csrc/pam_sync.hip)
+    //      must never reach the tracker state -- the reference's PersonPoseDetect (/root/reference/src/ivclabpose.py:208-212) cannot hand
+    //      out a frame it later disowns.  The word is raised on THIS device (A.guard) or travels with a view-sharded record (second double
+    //      of its count row, set by the rank that produced it).  A void frame leaves the state as it is; hdr[6] remembers the first frame
+    //      of the current run of void frames (+ 1) so that the host knows where to resume.
+    {
+        int voided = A.guard ? __hip_atomic_load(A.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        if (A.view_row)
+            for (int v = 0; v < d.C; ++v) voided |= (A.det[((size_t)A.view_row[v] * (d.MAXP + 1) + d.MAXP) * J3 + 1] != 0.0);
+        if (voided) {
+            if (threadIdx.x == 0) {
+                int* oi = A.out_i + (size_t)sidx * A.ol.int_words;
+                double* od = A.out_d + (size_t)sidx * A.ol.dbl_words;
+                if (st.hdr[6] == 0) st.hdr[6] = A.frame_id + 1;
+                oi[0] = 0; oi[1] = ST_INPUT_VOID | (st.hdr[5] << 16); oi[2] = A.frame_id; oi[3] = st.hdr[6] - 1;
+                const double t = now_s();
+                for (int k = 0; k < 12; ++k) od[k] = t;
+            }
+            return;
+        }
+    }
     if (A.hot_in_lds) {
         carve_ws_hot(hot_lds, d, ws);                                   // small scratch in LDS
         char* st_lds = hot_lds + hot_bytes(d);                          // integer scene state in LDS for this frame
@@ -621,6 +645,7 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
         // status word: bits 0-15 = this frame, bits 16-31 = OR over every frame since pam_create / pam_reset (a host that
         // only decodes the last record of a run still sees an overflow raised in any earlier frame)
         st.hdr[5] |= st.hdr[2];
+        st.hdr[6] = 0;                                  // a frame was applied: the run of void frames (input guard above), if any, is over
         out_i[0] = m; out_i[1] = (st.hdr[2] & 0xffff) | (st.hdr[5] << 16); out_i[2] = frame; out_i[3] = ws.misc[0];
     }
     __syncthreads();
@@ -781,6 +806,7 @@ struct PamHandle {
     PamOutLayout ol{};
     hipStream_t stream = nullptr;
     char* d_op = nullptr; size_t op_bytes = 0;     // staging for the per-operator entry points
+    const int* d_guard = nullptr;                  // pam_set_input_guard
     std::string err;
 };
 static std::string g_create_err;
@@ -891,11 +917,20 @@ extern "C" int pam_out_layout(const PamHandle* h, PamOutLayout* out) {
     return PAM_OK;
 }
 
+// The frame kernel skips a frame (record status bit 16, state untouched) while *dev_word != 0: dev_word is raised by whoever produced
+// the frame's keypoints when they are not valid (pam_flag_gate's dev_void).  NULL removes the guard.
+extern "C" int pam_set_input_guard(PamHandle* h, const int32_t* dev_word) {
+    if (!h) return PAM_E_ARG;
+    h->d_guard = dev_word;
+    return PAM_OK;
+}
+
 static int launch_frame(PamHandle* h, hipStream_t s, int frame_id, const int* d_ndet, const double* d_det, const int* d_view_row = nullptr) {
     if (!h->cams_set) { h->err = "pam_set_cameras has not been called"; return PAM_E_STATE; }
     FrameArgs A;
     A.d = h->d; A.cs = camset(h); A.prm = h->d_prm;
     A.state = h->d_state; A.state_stride = h->state_stride; A.ws = h->d_ws; A.ws_stride = h->ws_stride;
+    A.guard = h->d_guard;
     A.n_det = d_ndet; A.det = d_det; A.view_row = d_view_row; A.out_i = h->d_out_i; A.out_d = h->d_out_d; A.ol = h->ol; A.frame_id = frame_id;
     const size_t hot = hot_bytes(h->d) + ((state_int_bytes(h->d) + 15) & ~(size_t)15);
     A.hot_in_lds = hot <= 128 * 1024 ? 1 : 0;

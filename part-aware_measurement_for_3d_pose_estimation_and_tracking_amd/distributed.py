@@ -14,6 +14,39 @@ import torch.distributed as dist
 NUM_JOINTS = 17
 
 
+def device_identity(device):
+    """(host name, device identity) of a torch CUDA device: what tells whether two ranks drive the same GPU.  The identity is the device's
+    UUID where PyTorch reports one, else its PCI location."""
+    import socket
+    p = torch.cuda.get_device_properties(device)
+    ident = getattr(p, 'uuid', None)
+    if ident is None or str(ident) in ('', 'None'):
+        ident = (getattr(p, 'pci_domain_id', None), getattr(p, 'pci_bus_id', None), getattr(p, 'pci_device_id', None), p.name)
+    return socket.gethostname(), str(ident)
+
+
+_share_cache = {}
+
+
+def ranks_share_a_device(device, group=None, identity=None):
+    """True when two ranks of the (initialised) process group drive the same physical GPU -- decided from the devices' identities, not from
+    counts: a launcher that shows every rank ONE device (HIP_VISIBLE_DEVICES per rank) has device_count() == 1 on an 8-GPU node, and
+    world > device_count() called that sharing.  Collective (all_gather_object), cached per (group, device).  identity: override of this
+    rank's (host, device) pair (CPU tests)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return False
+    key = (id(group), str(device))
+    if identity is None and key in _share_cache:
+        return _share_cache[key]
+    me = identity if identity is not None else device_identity(device)
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, tuple(me), group=group)
+    shared = len(set(everyone)) < len(everyone)
+    if identity is None:
+        _share_cache[key] = shared
+    return shared
+
+
 def view_partition(n_views, world):
     """rank r owns the contiguous block {v : v * world // n_views == r} (may be empty when world > n_views)."""
     return [[v for v in range(n_views) if v * world // n_views == r] for r in range(world)]
@@ -68,6 +101,7 @@ class ViewGather(object):
             if (world > 1 or abi is not None) else self.send
         self.det_local = self.send[:max(1, len(self.mine))]            # contiguous: the leading records
         self.count_local = self.send[:, max_dets, 0, 0]               # strided view: one count per record
+        self.void_local = self.send[:, max_dets, 0, 1]                # ... and the producer's "these keypoints are void" word beside it
         rows = [0] * n_views
         for r, p in enumerate(self.parts):
             for i, v in enumerate(p):
@@ -75,12 +109,18 @@ class ViewGather(object):
         self.rows = torch.tensor(rows, dtype=torch.int32, device=device)
         self.rows_long = self.rows.long()
 
-    def exchange(self, n_det_local):
+    def exchange(self, n_det_local, void_word=None):
         """n_det_local (len(mine),) int tensor; the detection rows are already in ``send`` (det_local).  Returns ``recv`` -- every
-        rank's records, rank-major -- identical on every rank; read it through ``rows``."""
+        rank's records, rank-major -- identical on every rank; read it through ``rows``.
+        void_word: this rank's (1,) int32 device word that is non-zero when the forward that decoded these rows gave up
+        (HRNetPose.void_word): it travels in the second double of every record's count row, and the frame kernel of EVERY rank skips the
+        frame when any record carries it (csrc/pam_tracker.hip) -- the replicated trackers stay identical.  With one rank the frame
+        kernel reads the word itself (pam_set_input_guard)."""
         k = len(self.mine)
         if k:
             self.count_local[:k].copy_(n_det_local)                    # int -> float64 in the copy: one small kernel
+            if void_word is not None and (self.world > 1 or self.abi is not None):
+                self.void_local[:k].copy_(void_word.expand(k))
         if self.world == 1 and self.abi is None:
             return self.recv
         if self.abi is not None:
@@ -118,9 +158,12 @@ class CropGather(object):
     def __init__(self, n_views, max_dets, world, rank, device, group=None):
         self.C, self.max_dets, self.world, self.rank, self.group = n_views, max_dets, world, rank, group
         self.rows = n_views * max_dets
-        self.send = torch.zeros((n_views, max_dets, NUM_JOINTS, 3), dtype=torch.float64, device=device)
-        self.recv = torch.zeros((world, self.rows, NUM_JOINTS * 3), dtype=torch.float64, device=device)
+        # one spare row behind the keypoint rows: its first double carries the rank's void word through the exchange
+        self._send_all = torch.zeros((self.rows + 1, NUM_JOINTS * 3), dtype=torch.float64, device=device)
+        self.send = self._send_all[:self.rows].view(n_views, max_dets, NUM_JOINTS, 3)
+        self.recv = torch.zeros((world, self.rows + 1, NUM_JOINTS * 3), dtype=torch.float64, device=device)
         self.det = torch.zeros((n_views, max_dets, NUM_JOINTS, 3), dtype=torch.float64, device=device)
+        self.void_any = torch.zeros(1, dtype=torch.int32, device=device)     # after gather(): some rank's forward of this frame gave up
 
     @staticmethod
     def select_index(view_of, slot_of, n_views, max_dets, world):
@@ -134,13 +177,20 @@ class CropGather(object):
         for r, (a, b) in enumerate(parts):
             for i in range(a, b):
                 owner[int(view_of[i]) * max_dets + int(slot_of[i])] = r
-        return owner * rows + np.arange(rows, dtype=np.int64), parts
+        return owner * (rows + 1) + np.arange(rows, dtype=np.int64), parts
 
-    def gather(self, select):
-        """select: (C*max_dets,) int64 device tensor from select_index -> det (C, max_dets, 17, 3) float64, all ranks alike."""
+    def gather(self, select, void_word=None):
+        """select: (C*max_dets,) int64 device tensor from select_index -> det (C, max_dets, 17, 3) float64, all ranks alike.
+        void_word: this rank's (1,) int32 "my forward gave up" word (HRNetPose.void_word); ``void_any`` is then 1 on EVERY rank when any
+        rank's word was up -- the word the frame kernel is guarded by in this mode (FramePipeline), so the replicated trackers skip the
+        same frames."""
         if self.world > 1:
-            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
-            torch.index_select(self.recv.view(self.world * self.rows, -1), 0, select, out=self.det.view(self.rows, -1))
+            if void_word is not None:
+                self._send_all[self.rows, :1].copy_(void_word)
+            dist.all_gather_into_tensor(self.recv.view(-1), self._send_all.view(-1), group=self.group)
+            torch.index_select(self.recv.view(self.world * (self.rows + 1), -1), 0, select, out=self.det.view(self.rows, -1))
+            if void_word is not None:
+                self.void_any.copy_(self.recv[:, self.rows, 0].amax().reshape(1))
             return self.det
         return self.send
 

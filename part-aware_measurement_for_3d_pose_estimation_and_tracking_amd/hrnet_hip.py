@@ -878,7 +878,20 @@ class HipHRNet(ConvEngine):
     flags_on = False            # state: this forward is being issued with flags
     flag_host_err = None        # pinned int32 word that receives 1 when a gate of ANY replay times out (HRNetPose reads it before every replay)
     flag_max_us = 2000000       # a gate gives up after 2 s (a systematic deadlock, found by the check after the first replay) and raises the error word
+    flag_dev_void = None        # device int32 word that receives 1 at any time-out: what the frame kernel's input guard reads (HRNetPose.void_word)
+    _flag_limit = None          # the bound as a device word the gates read when they start (set_flag_limit changes it for captured gates too)
     _flags = None
+
+    def flag_limit(self):
+        if self._flag_limit is None:
+            self._flag_limit = torch.tensor([int(self.flag_max_us)], dtype=torch.int32, device=self.device)
+        return self._flag_limit
+
+    def set_flag_limit(self, us):
+        """Bound (microseconds) of every gate that STARTS after the current stream's work so far, captured ones included (tests force a
+        time-out in replay k this way; 0 = give up at the first poll that finds a branch missing)."""
+        self.flag_max_us = int(us)
+        self.flag_limit().fill_(int(us))
 
     def _flag_begin(self):
         """counters + error word of ONE forward (word 0 = error); zeroed on the caller's stream in front of the fork -- inside a capture the
@@ -901,8 +914,9 @@ class HipHRNet(ConvEngine):
 
     def _gate(self, i, target, arrive=False):
         rc = self.lib.pam_flag_gate(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.c_void_p(self._flags.data_ptr() + 4 * i),
-                                    int(target), C.c_void_p(self._flags.data_ptr()), int(self.flag_max_us), 1 if arrive else 0,
-                                    C.c_void_p(self.flag_host_err.data_ptr()) if self.flag_host_err is not None else None)
+                                    int(target), C.c_void_p(self._flags.data_ptr()), C.c_void_p(self.flag_limit().data_ptr()), 1 if arrive else 0,
+                                    C.c_void_p(self.flag_host_err.data_ptr()) if self.flag_host_err is not None else None,
+                                    C.c_void_p(self.flag_dev_void.data_ptr()) if self.flag_dev_void is not None else None)
         if rc != 0:
             raise _lib.PamError('pam_flag_gate failed (%d)' % rc)
 

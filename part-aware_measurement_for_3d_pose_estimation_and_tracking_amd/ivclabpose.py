@@ -128,6 +128,8 @@ class ivclabpose(object):
                              ('arm_sigma', 'ARM_SIGMA')):
                 a[dst] = _cfg(m, src)
             self.tracker = IterativeTracker(a, max_dets=max_dets, max_tracks=max_tracks, device=device)
+            if self.pose_model is not None:
+                self.tracker.set_input_guard(self.pose_model)      # keypoints of a forward whose gate timed out never reach the tracker state
             print("Person Matcher : ", _cfg(m, 'NAME'))
 
     # -- a18 ----------------------------------------------------------------------------------------------------------
@@ -184,7 +186,8 @@ class ivclabpose(object):
             # the dump is the one PersonPoseDetect returned, untouched: its keypoints are still on the device in the tracker's
             # layout -> no re-packing, no host -> device copy (the dicts stay the source of truth whenever the caller edits them)
             # (the frame kernel is queued first: the one host wait of this call, behind it, also covers the keypoints' copy predict() enqueued)
-            asso_time, update_time, init_time = self.tracker.tracking_dev(frame_id, self.cameras, dump_results.device_n_det, dev, build3D)
+            asso_time, update_time, init_time = self.tracker.tracking_dev(frame_id, self.cameras, dump_results.device_n_det, dev, build3D,
+                                                                          on_void=getattr(dump_results, 'redo_if_void', None))
             poses = dump_results.poses_host
         else:
             poses = self._unpack(dump_results)

@@ -71,10 +71,19 @@ class FramePipeline(object):
         self._frame_no = 0
         # device-side gates (pam_sync.hip) need the forward to be the only flagged work on the device: two forwards in flight can block
         # each other's queues, and so can the replays of several ranks that share one device (more ranks than devices: one-device tests)
-        if self.net is not None and (self.pose_streams is not None or world > torch.cuda.device_count()):
+        # (which ranks share one is decided from the devices' identities: a launcher that shows each rank a single device has device_count() == 1)
+        from .distributed import ranks_share_a_device
+        self.shared_device = ranks_share_a_device(self.device, group) if world > 1 else False
+        if self.net is not None and (self.pose_streams is not None or self.shared_device):
             self.net.disable_flag_sync()
         if self.net is not None:
             self.net.flag_race = 'throughput'        # the pipeline keeps the host a frame ahead of the device: time the flag race that way
+            # Keypoints of a forward whose gate gave up must not reach the tracker state.  The host runs a frame ahead and cannot look, so
+            # the frame kernel does: it skips every frame while the producer's void word is up (pam_set_input_guard; results() then raises
+            # FrameVoid with the frame to resume from).  Sharded: the word travels with the exchange, so that every rank's replica skips
+            # the same frames -- inside the view records (ViewGather.exchange), or as CropGather.void_any, which is the guard there.
+            guard = self.crop_gather.void_any if (shard == 'crops' and world > 1) else self.net.void_word
+            self.handle.set_input_guard(guard.data_ptr())
         self.bucketed, self.warmed = bool(prewarm), None
         if prewarm and self.net is not None:
             most = (self.C if shard == 'crops' else len(self.mine)) * max_dets
@@ -236,7 +245,7 @@ class FramePipeline(object):
             self.write_local(det_local)
 
         def issue(st):
-            recv = self.gather.exchange(n_det_local)
+            recv = self.gather.exchange(n_det_local, self.net.void_word if self.net is not None else None)
             self.handle.frame_dev_views(st, frame_id, recv.data_ptr(), self.gather.rows.data_ptr())
             if fetch:
                 self.handle.fetch(st, self.out_i.numpy(), self.out_d.numpy())
@@ -272,8 +281,9 @@ class FramePipeline(object):
     def track_step_crops(self, frame_id, n_det, select, fetch=True):
         """n_det (C,) int32 and select (CropGather.select_index) are the same on every rank (they follow from the frame's box
         list); the keypoint rows come from ``crop_gather.send`` of the rank that owns each crop."""
+        vw = self.net.void_word if self.net is not None else None
         if self.track_stream is None:
-            det = self.crop_gather.gather(select)
+            det = self.crop_gather.gather(select, vw)
             st = self.stream_ptr()
             self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
             if fetch:
@@ -282,7 +292,7 @@ class FramePipeline(object):
         self.ev_pose.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.track_stream):
             self.track_stream.wait_event(self.ev_pose)
-            det = self.crop_gather.gather(select)
+            det = self.crop_gather.gather(select, vw)
             st = self.track_stream.cuda_stream
             self.handle.frame_dev(st, frame_id, n_det.data_ptr(), det.data_ptr())
             if fetch:
@@ -301,6 +311,13 @@ class FramePipeline(object):
             self.track_stream.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
         rec = self.handle.decode(0, self.out_i.numpy(), self.out_d.numpy())
+        if rec['status'] & _lib.ST_INPUT_VOID:
+            # a gate of a captured forward timed out in frame rec['first_void']: the tracker (every rank's replica) skipped that frame and
+            # all since; the network is on stream events by now (HRNetPose.check_void).  Lower the word and tell the caller where to resume.
+            if self.net is not None:
+                self.net.check_void()
+                self.net.clear_void()
+            raise _lib.FrameVoid(rec['first_void'], rec['frame_id'])
         if strict and (rec['status'] | rec['status_sticky']) != 0:
             raise _lib.PamError('tracker status 0x%x on frame %d, 0x%x over the run (1 track slots, 2 hypothesis slots, 4 infeasible '
                                 'assignment, 8 clamped detection count)' % (rec['status'], rec['frame_id'], rec['status_sticky']))

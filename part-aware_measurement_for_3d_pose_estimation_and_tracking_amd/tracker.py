@@ -68,6 +68,7 @@ class IterativeTracker(object):
         self.cameras = None
         self.tracks = []
         self.last = None
+        self._guard = None           # set_input_guard: the pose network whose void word the frame kernel reads
         if n_views is not None:
             self._open(n_views)
 
@@ -82,6 +83,15 @@ class IterativeTracker(object):
         L = self.handle.layout
         self._rec_i = torch.zeros((1, L.int_words), dtype=torch.int32).pin_memory()
         self._rec_d = torch.zeros((1, L.dbl_words), dtype=torch.float64).pin_memory()
+        if self._guard is not None:
+            self.handle.set_input_guard(self._guard.void_word.data_ptr())
+
+    def set_input_guard(self, net):
+        """net: the HRNetPose whose decode feeds this tracker (None removes the guard).  While its ``void_word`` is raised -- a device-side
+        gate of one of its captured forwards timed out -- the frame kernel does not apply frames (record status ST_INPUT_VOID)."""
+        self._guard = net
+        if self.handle is not None:
+            self.handle.set_input_guard(net.void_word.data_ptr() if net is not None else None)
 
     def set_cameras(self, cameras):
         if self.handle is None or self.cam_num != len(cameras):
@@ -110,11 +120,19 @@ class IterativeTracker(object):
                 self._det[0, v, :n] = dets
         self.handle.frame(frame_id, self._ndet, self._det)
         self.last = self.handle.decode(0)
+        if self.last['status'] & _lib.ST_INPUT_VOID:
+            # host keypoints are valid by construction (DumpResults re-ran a void forward before handing them out); the word was left
+            # raised by a forward nobody consumed: lower it and apply the frame
+            if self._guard is None:
+                raise _lib.PamError('frame %d was skipped: the input guard word is raised and no pose network is attached' % frame_id)
+            self._guard.check_void(); self._guard.clear_void()
+            self.handle.frame(frame_id, self._ndet, self._det)
+            self.last = self.handle.decode(0)
         self.tracks = [TrackView(r, self.cameras, detections_list) for r in self.last['tracks']]
         c = self.last['clocks']
         return float(c[1] - c[0]), float(c[2] - c[1]), float(c[3] - c[2])
 
-    def tracking_dev(self, frame_id, camera_list, dev_n_det, dev_det, build3D='SVD'):
+    def tracking_dev(self, frame_id, camera_list, dev_n_det, dev_det, build3D='SVD', on_void=None):
         """The same step on detections that are already on the device: dev_n_det (views,) int32, dev_det (views, max_dets, 17, 3)
         float64 rows (y, x, score) CUDA tensors (what ``HRNetPose.predict`` keeps) -> no host packing, no host -> device copy;
         one launch + one device -> host copy of the record."""
@@ -125,14 +143,19 @@ class IterativeTracker(object):
         if tuple(dev_det.shape) != (self.cam_num, self.max_dets, NUM_JOINTS, 3) or dev_det.dtype != torch.float64 or \
                 dev_n_det.dtype != torch.int32 or not dev_det.is_contiguous():
             raise _lib.PamError('device detections %s do not match the tracker (%d views, max_dets=%d)' % (tuple(dev_det.shape), self.cam_num, self.max_dets))
-        st = torch.cuda.current_stream(dev_det.device).cuda_stream
-        self.handle.frame_dev(st, frame_id, dev_n_det.data_ptr(), dev_det.data_ptr())
         oi, od = self._rec_i.numpy(), self._rec_d.numpy()
-        self.handle.fetch(st, oi, od)
-        self.handle.sync(st)
-        self.last = self.handle.decode(0, oi, od)
+        for attempt in (0, 1):
+            st = torch.cuda.current_stream(dev_det.device).cuda_stream
+            self.handle.frame_dev(st, frame_id, dev_n_det.data_ptr(), dev_det.data_ptr())
+            self.handle.fetch(st, oi, od)
+            self.handle.sync(st)
+            self.last = self.handle.decode(0, oi, od)
+            # on_void: the keypoints' producer re-runs its forward into the same device buffers (DumpResults.redo_if_void) -- the frame
+            # kernel skipped the frame (state untouched), so the second attempt is the frame's first application
+            if not (self.last['status'] & _lib.ST_INPUT_VOID) or attempt == 1 or on_void is None or not on_void():
+                break
         if self.last['status'] != 0:
-            raise _lib.PamError('tracker status 0x%x (capacity overflow / infeasible assignment) on frame %d' % (self.last['status'], frame_id))
+            raise _lib.PamError('tracker status 0x%x (1 / 2 capacity overflow, 4 infeasible assignment, 8 clamped count, 16 void input) on frame %d' % (self.last['status'], frame_id))
         self.tracks = [TrackView(r, self.cameras, None) for r in self.last['tracks']]
         c = self.last['clocks']
         return float(c[1] - c[0]), float(c[2] - c[1]), float(c[3] - c[2])

@@ -134,3 +134,43 @@ def test_surface_keypoint_gather_world2_gloo():
     ret = mgr.dict()
     mp.spawn(_kp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def _void_worker(rank, world, port, ret):
+    """The producer's "these keypoints are void" word through both exchanges: raised on ONE rank it must be seen by every rank -- in every
+    view record's count row (what the frame kernel checks, csrc/pam_tracker.hip) and as CropGather.void_any -- and be gone the frame after
+    it was lowered; and the device-sharing rule decided from identities."""
+    from pam.distributed import ranks_share_a_device
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    C, md = 5, 4
+    cpu = torch.device('cpu')
+    vg, cg = ViewGather(C, md, world, rank, cpu), CropGather(C, md, world, rank, cpu)
+    word = torch.zeros(1, dtype=torch.int32)
+    select = torch.tensor(CropGather.select_index([0, 1, 2], [0, 0, 0], C, md, world)[0])
+    ok = True
+    for t, raised_on in enumerate((None, 1, None, 0, None)):
+        word.fill_(1 if raised_on == rank else 0)
+        recv = vg.exchange(torch.ones(len(vg.mine), dtype=torch.int32), word)
+        flags = [float(recv[int(vg.rows[v]), md, 0, 1]) for v in range(C)]
+        owner = [r for v in range(C) for r, p in enumerate(vg.parts) if v in p]
+        ok &= flags == [1.0 if owner[v] == raised_on else 0.0 for v in range(C)]
+        ok &= all(float(recv[int(vg.rows[v]), md, 0, 0]) == 1.0 for v in range(C))           # the counts beside them are untouched
+        cg.gather(select, word)
+        ok &= int(cg.void_any) == (0 if raised_on is None else 1)
+    # two ranks, two devices -> not shared; two ranks, one identity -> shared (what world > device_count() could not tell apart under
+    # HIP_VISIBLE_DEVICES: there every rank counts one device)
+    ok &= ranks_share_a_device(cpu, identity=('host', 'gpu-%d' % rank)) is False
+    ok &= ranks_share_a_device(cpu, identity=('host', 'gpu-0')) is True
+    ok &= ranks_share_a_device(cpu, identity=('host-%d' % rank, 'gpu-0')) is False
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_void_word_travels_with_both_exchanges_and_device_sharing_is_decided_from_identities_gloo():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_void_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]

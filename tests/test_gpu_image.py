@@ -618,69 +618,3 @@ def test_preprocess_antialias_matches_the_pil_formula(net):
     assert float(x[:, 3:].float().abs().max()) == 0.0
 
 
-_FLAG_CHILD = r"""
-import sys
-sys.path.insert(0, %r)
-import torch
-import pam
-from pam import hrnet, _lib
-a = hrnet.HRNetPose(48, 17, None, use_graph=False)
-b = hrnet.HRNetPose(48, 17, None, use_graph=True)
-b.flag_race = None                                  # no race against stream events: this object keeps its flagged captures
-x = a.input_buffer(5)
-x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(x.device).to(x.dtype)); x[:, 3:] = 0
-ref = a.features(x).clone()
-for _ in range(10):
-    y = b.features(x)
-torch.cuda.synchronize()
-assert b.flag_synced[(5, 'features', 0)] is True, (b.flag_synced, getattr(b, '_flag_sync_failed', None))
-assert torch.equal(ref, y)
-assert b.captures == 1 and len(b._dead_graphs) == 0 and int(b._flag_host_np[0]) == 0
-# every flagged capture has the stream-event form of the same forward beside it; both are timed one at a time and back to back, and a
-# replay uses the form that is faster the way the object is used at that moment (flag_race); a second slot follows the verdict
-d = hrnet.HRNetPose(48, 17, None, use_graph=True)
-for mode in ('serial', 'throughput', 'serial'):
-    d.flag_race = mode
-    yd = d.features(x).clone(); torch.cuda.synchronize()
-    t = d.flag_timing[5]
-    assert all(t['kept'][m] == (t['ms'][m][0] <= t['ms'][m][1]) for m in ('serial', 'throughput'))
-    assert len(d._dead_graphs) == 0 and set(d._alt[(5, 'features', 0)]) == {'flags', 'events'} and torch.equal(ref, yd)
-    y1 = d.features(x, slot=1).clone(); torch.cuda.synchronize()
-    assert torch.equal(ref, y1) and d.captures == 2
-# a time-out in a LATER replay reaches the host through the pinned word: the next call raises and the object falls back
-b._flag_host_np[0] = 1
-try:
-    b.features(x)
-    raise SystemExit('no PamError')
-except _lib.PamError as e:
-    assert 'gate' in str(e)
-y4 = b.features(x).clone(); torch.cuda.synchronize()
-assert b.flag_synced[(5, 'features', 0)] is False and torch.equal(ref, y4)
-print('FLAGS-OK')
-"""
-
-
-def test_replays_order_their_branch_streams_by_device_flags_and_fall_back_when_a_gate_times_out():
-    """Captured forwards meet at the module ends through counters in device memory (csrc/pam_sync.hip) instead of stream events: same
-    features as the eager forward (which uses stream events), error word zero over many replays; the capture-time race; the host word.
-    In a FRESH process: whether the chains of a graph get hardware queues of their own depends on how many streams the process has made
-    (a pytest session has made dozens; a flagged capture whose check times out there falls back to stream events, which is the second
-    half of this test).  Then, in this process: a capture whose first replay raises the error word (here: a time-out of 1 us, which every
-    gate exceeds) is replaced by one with stream events, with the same result."""
-    import subprocess
-    import sys
-    from pam import hrnet
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, '-c', _FLAG_CHILD % root], capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0 and 'FLAGS-OK' in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
-    a = hrnet.HRNetPose(48, 17, None, use_graph=False)
-    x = a.input_buffer(5)
-    x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(x.device).to(x.dtype)); x[:, 3:] = 0
-    ref = a.features(x).clone()
-    c = hrnet.HRNetPose(48, 17, None, use_graph=True)
-    c.hip.flag_max_us = 1
-    y2 = c.features(x).clone()
-    torch.cuda.synchronize()
-    assert c.flag_synced[(5, 'features', 0)] is False and c.captures == 1 and len(c._dead_graphs) == 1 and torch.equal(ref, y2)
-    assert c._flag_sync_ok() is False                   # and the object stays with stream events
-    assert int(c._flag_host_np[0]) == 0                 # the time-outs of the checked replay were dealt with there

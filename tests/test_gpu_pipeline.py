@@ -238,3 +238,53 @@ def test_prewarmed_pipeline_never_captures_inside_a_step():
         torch.cuda.synchronize()
         assert torch.equal(a, plain.crop_gather.send), t
     assert len(seen) >= 4, seen
+
+
+def test_input_guard_skips_frames_leaves_the_state_untouched_and_names_the_first_void_frame():
+    """pam_set_input_guard: while the producer's device word is up -- or any view record of a sharded frame carries the flag -- the frame
+    kernel applies nothing: record status 16, no tracks, word [3] = the first frame of the run of void frames; once the word is down
+    the re-submitted frames give exactly the records of a run that never saw it."""
+    from pam import synth, _lib
+    from pam.pipeline import FramePipeline
+    seq, cams, cfg, conf, meta = _rig('S2')
+    C, md = meta['C'], 8
+    n_det_all, det_all = synth.pack_frames(seq['frames'], md)
+    ref = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False)
+    new = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, hrnet=False)
+    dev = ref.device
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+    new.handle.set_input_guard(word.data_ptr())
+    F = len(seq['frames'])
+    want = []
+    for t in range(F):
+        ref.track_step(t, torch.tensor(n_det_all[t], dtype=torch.int32, device=dev), torch.tensor(det_all[t], dtype=torch.float64, device=dev))
+        want.append(ref.results())
+
+    def step(t):
+        new.track_step(t, torch.tensor(n_det_all[t], dtype=torch.int32, device=dev), torch.tensor(det_all[t], dtype=torch.float64, device=dev))
+        return new.results()
+
+    def same(a, b):
+        assert a['n_tracks'] == b['n_tracks'] and a['status'] == b['status'] == 0 and a['frame_id'] == b['frame_id']
+        for ta, tb in zip(a['tracks'], b['tracks']):
+            assert ta['track_id'] == tb['track_id'] and ta['hits'] == tb['hits'] and ta['age'] == tb['age'] and ta['state'] == tb['state']
+            assert np.array_equal(ta['pose3d'], tb['pose3d']) and np.array_equal(ta['velocity'], tb['velocity'])
+    for t in range(12):
+        same(step(t), want[t])
+    word.fill_(1)                                            # the device word (one rank: the frame kernel reads it itself)
+    for t in (12, 13, 14):
+        with pytest.raises(_lib.FrameVoid) as e:
+            step(t)
+        assert (e.value.first, e.value.last) == (12, t)
+        rec = new.handle.decode(0, new.out_i.numpy(), new.out_d.numpy())
+        assert rec['status'] == _lib.ST_INPUT_VOID and rec['n_tracks'] == 0 and rec['status_sticky'] == 0
+    word.zero_()
+    for t in range(12, 20):
+        same(step(t), want[t])
+    new.gather.send[1, md, 0, 1] = 1.0                       # the flag inside a view record (what a rank's exchange carries)
+    with pytest.raises(_lib.FrameVoid) as e:
+        step(20)
+    assert (e.value.first, e.value.last) == (20, 20)
+    new.gather.send[1, md, 0, 1] = 0.0
+    for t in range(20, F):
+        same(step(t), want[t])
