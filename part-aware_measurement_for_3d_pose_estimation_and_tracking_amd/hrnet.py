@@ -330,6 +330,7 @@ class HRNetPose(object):
         # with the frame to resume from) -- check_void / clear_void below.
         self.void_word = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.hip.flag_dev_void = self.void_word
+        self.hip.flag_limit()                             # (the gates' bound as a device word: made here, never inside a capture)
         self.void_pending = False    # a time-out has been seen and the forwards since have not been re-run yet
         self.flag_timeouts = 0       # time-outs seen by this object after the capture-time checks
         if self.world > 1:
