@@ -60,6 +60,8 @@ def parse_args():
     ap.add_argument('--no-h2d', action='store_true', help='skip the second timed run with the frames starting in pinned host memory')
     ap.add_argument('--no-drift', action='store_true')
     ap.add_argument('--no-full', action='store_true', help='skip the full-pipeline runs (person detector in the loop)')
+    ap.add_argument('--no-driver-loop', action='store_true', help='skip the loop of pam/testmodel.py (JPEG files -> loader -> detect -> pose -> track)')
+    ap.add_argument('--no-ab', action='store_true', help="skip the interleaved A/B of this round's executor against the previous round's")
     ap.add_argument('--no-pair', action='store_true', help='skip the throughput-mode run (two frames per conv-stack replay)')
     ap.add_argument('--no-extra', action='store_true', help='N > 1: skip the crop-balanced run, the single-GPU run of the same workload and the Panoptic-31 runs')
     ap.add_argument('--batched-scenes', type=int, default=2048)
@@ -392,6 +394,10 @@ def full_pipeline_runs(torch, dist, pipe, inp, K, W, C, fh, fw, dev, ref_tracks)
 
     # throughput mode of the detector (like value_2frames_per_forward for the pose network): the views of frames t + 1 AND t + 2 in one
     # detector replay every other frame (2 C views per launch: the 80-launch chain is paid once per two frames)
+    # (the 2 C-view graph first, on a temporary tensor, THEN its own input buffer: frame_buffer() before the capture hands out a fresh tensor
+    # and every replay would pay a device-to-device copy of 2 C frames into the graph's static input -- ADVICE r5)
+    det.detect_dev(torch.cat([frames, frames]).contiguous())
+    torch.cuda.synchronize()
     buf2 = det.frame_buffer(2 * C, fh, fw)
     buf2[:C].copy_(frames); buf2[C:].copy_(frames)
     det.detect_dev(buf2)
@@ -642,6 +648,8 @@ def main():
                                  'algorithmic_bytes': work[n_med]['bytes'] if n_med in work else None,
                                  'bytes_as_executed': work[n_med]['bytes_as_executed'] if n_med in work else None}},
             'final_tracks': [t['track_id'] for t in final['tracks'] if t['emitted']], 'tracker_status': final['status'] | final['status_sticky'],
+            # one scene, one launch: in-kernel clocks of the last frame's k_frame (start of P0 .. end of the record)
+            'k_frame_us': float(final['clocks_all'][11] - final['clocks_all'][0]) * 1e6,
         }
 
     # ---- N > 1: the same frames with the other partition, rank 0 running the whole frame alone, and the Panoptic-31 workload -------------
@@ -706,6 +714,10 @@ def main():
         if not args.no_surface and world == 1:
             out['surface'] = surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, min(K, 60), min(W, 5))
             out['surface']['frac_of_value'] = out['surface']['value'] / out['value']
+        if not args.no_driver_loop and world == 1 and shard == 'crops' and pipe.net is not None:
+            out['driver_loop'] = driver_loop(torch, synth, pipe, cams, cfg, conf, inp, size, max_dets, min(K, 60), min(W, 5))
+        if not args.no_ab and world == 1 and pipe.net is not None and n_med > 0:
+            out['ab_vs_previous_round'] = ab_vs_previous_round(torch, hrnet_mod, pipe.net, n_med, dev)
         if not args.no_drift and world == 1 and pipe.net is not None and pipe.net.backend == 'hip':
             out['hrnet_drift'] = hrnet_mod.measure_bf16_drift(pipe.net, n_crops=2)
         if not args.no_batched:
@@ -713,10 +725,51 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(torch, synth, hrnet_mod, seq, cfg, conf, Fm, crops_per_frame)
             out['config']['gpu_over_cpu'] = out['value'] / out['cpu_baseline']['value']
+        out['summary'] = summary_of(out, pipe, n_med)      # LAST: the driver keeps the tail of the line
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def summary_of(out, pipe, n_med):
+    """Flat digest (< 1.5 KB) of the line, emitted as its LAST key: the driver's record keeps the final 2 000 characters of stdout, so
+    this is what survives of everything but the contract fields."""
+    def r(x, k=3):
+        return None if x is None else round(float(x), k)
+    g = out.get
+    rf, full, sf, tb, ab, dl, cb = g('roofline') or {}, g('full_pipeline') or {}, g('surface') or {}, g('tracker_batched') or {}, \
+        g('ab_vs_previous_round') or {}, g('driver_loop') or {}, g('cpu_baseline') or {}
+    hb = rf.get('hbm') or {}
+    net = pipe.net
+    race = (net.flag_timing.get(n_med) if net is not None else None) or {}
+    ms = race.get('ms') or {}
+    clk = g('clock_mhz') or {}
+    det = full.get('detector') or {}
+    s = {
+        'value': r(g('value'), 1), 'ms_per_step': r(g('ms_per_step')), 'conv_stack_ms': r((g('conv_stack_ms') or {}).get('median')),
+        'roofline_frac': r(rf.get('frac'), 4), 'launches': None,
+        'traffic_over_algorithmic': r(rf['traffic'] / hb['algorithmic_bytes']) if rf.get('traffic') and hb.get('algorithmic_bytes') else None,
+        'crops': n_med,
+        'flags_ms': [r(ms[m][0]) for m in ('serial', 'throughput')] if ms else None,
+        'events_ms': [r(ms[m][1]) for m in ('serial', 'throughput')] if ms else None,
+        'flags_kept': [bool(race['kept'][m]) for m in ('serial', 'throughput')] if race else None,
+        'flag_timeouts': net.flag_timeouts if net is not None else None,
+        'clock_mhz': [r(clk.get('before'), 0), r(clk.get('after'), 0)],
+        'value_full_pipeline': r(full.get('value'), 1), 'full_serial': r((full.get('serial') or {}).get('value'), 1),
+        'detector_ms': r(det.get('ms')), 'detector_frac': r(det.get('frac'), 4), 'detector_hidden': r(full.get('hidden_frac_of_detector'), 2),
+        'surface': r(sf.get('value'), 1), 'surface_frac': r(sf.get('frac_of_value')), 'surface_form': sf.get('forward_form'),
+        'surface_fwd_ms': r(sf.get('forward_ms_one_at_a_time')), 'surface_host_ms': r(sf.get('host_and_rest_ms')),
+        'driver_loop': r(dl.get('value'), 1), 'driver_loop_serial': r((dl.get('serial') or {}).get('value'), 1),
+        'driver_loop_bound': (dl.get('ahead') or {}).get('bound_by'), 'loader_alone': r(dl.get('loader_alone_frame_sets_per_s'), 1),
+        'k_frame_batched_us': r(tb.get('us_per_launch'), 1), 'tracker_batched_frac': r(tb.get('frac'), 4),
+        'k_frame_us': r(g('k_frame_us'), 1),
+        'ab_ms_default': r(ab.get('ms_default')), 'ab_ms_previous': r(ab.get('ms_previous')), 'ab_ratio': r(ab.get('ratio'), 4),
+        'value_2frames': r(g('value_2frames_per_forward'), 1), 'value_h2d': r(g('value_with_h2d'), 1),
+        'cpu_fps': r(cb.get('value')), 'cpu_cores': cb.get('cores'),
+    }
+    s['launches'] = int(rf['kernel'].split(' launches')[0].split()[-1]) if rf.get('kernel') and ' launches' in rf['kernel'] else None
+    return s
 
 
 def hbm_traffic(n_crops, launches):
@@ -832,9 +885,195 @@ def surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, K
         el = time.perf_counter() - t0
     finally:
         pipe.net.flag_race = race_mode
+    # where a surface step goes: the forward alone, one replay at a time, in the form this loop used (device time; the crop / head / frame
+    # kernels add ~0.1 ms) against the wall time of a step -- the rest is the host (tables, launches, the 9-tuple) and idle gaps
+    n_med = int(np.median([len(sum(p, [])) for p in pbls[W:]]))
+    nb = pipe.net.bucket(n_med, max(20, n_med)) if hasattr(pipe.net, 'bucket') else n_med
+    key = (nb, 'features', 0)
+    form, fwd_ms = None, None
+    if key in pipe.net._graphs:
+        alt = pipe.net._alt.get(key)
+        form = ('flags' if pipe.net.flag_timing[nb]['kept']['serial'] else 'events') if alt is not None else ('flags' if pipe.net.flag_synced.get(key) else 'events')
+        g = alt[form][0] if alt is not None else pipe.net._graphs[key][0]
+        fwd_ms = float(np.median([pipe.net._replay_ms(g, 'serial') for _ in range(5)]))
     return {'value': K / el, 'unit': 'frames/s', 'ms_per_step': el / K * 1e3, 'steps': K, 'emitted_poses': emitted,
+            'forward_form': form, 'forward_ms_one_at_a_time': fwd_ms, 'host_and_rest_ms': (el / K * 1e3 - fwd_ms) if fwd_ms else None,
             'what': 'ivclabpose.PersonPoseDetect + PersonTrack_Project3DPose per frame (host lists out of predict, 9-tuple out of the tracker; '
                     'keypoints handed over on the device)'}
+
+
+def write_synthetic_jpegs(root, C, fh, fw, n_sets, seed=7):
+    """n_sets frame sets of C camera images as JPEG files under root/cam<v>/ -- smooth synthetic content (up-scaled low-resolution noise
+    plus a few rectangles) so that file size and decode cost are those of photographs, not of white noise.  -> list over sets of C paths."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    sets = []
+    for k in range(n_sets):
+        files = []
+        for v in range(C):
+            d = os.path.join(root, 'cam%d' % v)
+            os.makedirs(d, exist_ok=True)
+            low = rng.integers(0, 256, size=(fh // 24 + 1, fw // 24 + 1, 3), dtype=np.uint8)
+            im = Image.fromarray(low).resize((fw, fh), Image.BICUBIC)
+            a = np.asarray(im).copy()
+            for _ in range(6):
+                x0, y0 = int(rng.integers(0, fw - 80)), int(rng.integers(0, fh - 160))
+                a[y0:y0 + 160, x0:x0 + 80] = rng.integers(0, 256, size=3, dtype=np.uint8)
+            a = np.clip(a.astype(np.int16) + rng.integers(-6, 7, size=a.shape, dtype=np.int16), 0, 255).astype(np.uint8)    # sensor noise
+            f = os.path.join(d, '%06d.jpg' % k)
+            Image.fromarray(a).save(f, quality=90)
+            files.append(f)
+        sets.append(files)
+    return sets
+
+
+def driver_loop(torch, synth, pipe, cams, cfg, conf, inp, size, max_dets, K, W):
+    """ONE number for the loop the reference ships (/root/reference/src/testmodel.py:51-69,92-98), as pam/testmodel.py runs it: JPEG files
+    on disk -> FrameLoader (worker threads decode ahead into pinned memory, a copy stream uploads) -> PersonDetect (YOLOv3, random
+    weights) -> PersonPoseDetect (HRNet-W48) -> PersonTrack_Project3DPose, the 9-tuple on the host every frame, with the per-stage times
+    the reference prints and which stage bounds the loop.  Two orders: `serial` = the reference's (detect, pose, track one after the
+    other) and `ahead` = pam/testmodel.py's default: frame t + 1's detection issued before frame t's pose network (PersonDetectAhead).
+    As everywhere in this file the random-weight detector's boxes and the random-weight network's keypoints are computed and then
+    replaced by the seeded ones (on the device), so that the tracker sees people."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    from pam.ingest import FrameLoader
+    from pam.ivclabpose import ivclabpose
+    dev = pipe.device
+    C = len(cams)
+    meta = synth.SIZES[size]
+    fh, fw = meta['h'], meta['w']
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)
+    try:
+        q = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q[0] != 'max':
+            usable = max(1, min(usable, int(float(q[0]) / float(q[1]) + 0.5)))
+    except Exception:
+        pass
+    workers = max(2, min(16, usable))
+    tmp = tempfile.mkdtemp(prefix='pam_jpeg_')
+    try:
+        n_sets = 8
+        sets = write_synthetic_jpegs(tmp, C, fh, fw, n_sets)
+        jpeg_bytes = int(np.mean([sum(os.path.getsize(f) for f in fs) for fs in sets]))
+        files = [sets[t % n_sets] for t in range(K + W)]
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ivclabpose({'NAME': 'YOLOv3', 'CFG': None, 'WEIGHT': None, 'CLASS_NAMES': None, 'SCORE_THRESH': 0.7, 'NMS_THRESH': 0.45},
+                               None, dict(cfg, NAME='Iterative'), conf, max_dets=max_dets, max_tracks=16, device=dev.index)
+        model.pose_model = pipe.net
+        model.pose_model.max_dets = max_dets
+        model.tracker.set_input_guard(pipe.net)
+        model.cameras = cams
+        model.tracker.set_cameras(cams)
+        det_dev = [torch.tensor(inp['det_all'][t], dtype=torch.float64, device=dev) for t in range(K + W)]
+        det_host = [[inp['det_all'][t][v][:inp['n_det_all'][t][v]] for v in range(C)] for t in range(K + W)]
+        boxes = []
+        for t in range(K + W):
+            e = inp['per_frame'][t]
+            boxes.append((e['vl'].tolist(), e['bx'].tolist()))
+
+        # the loader alone over the same files (decode + upload, nothing consuming): its ceiling
+        ld = FrameLoader('Shelf', files, workers=workers, device=dev)
+        t0 = time.perf_counter()
+        for _ in ld:
+            pass
+        torch.cuda.synchronize()
+        loader_alone = (K + W) / (time.perf_counter() - t0)
+        ld.close()
+
+        def run(ahead_mode):
+            model.tracker.track_restart()
+            loader = FrameLoader('Shelf', files, workers=workers, device=dev)
+            it = iter(loader)
+            tl = td = tp = tt = 0.0
+            t0 = time.perf_counter(); cur = next(it, None); first_wait = time.perf_counter() - t0
+            ticket, emitted, k, t_start = None, 0, 0, None
+            while cur is not None:
+                if k == W:
+                    torch.cuda.synchronize()
+                    tl = td = tp = tt = 0.0
+                    t_start = time.perf_counter()
+                t, imagelist, _ = cur
+                a = time.perf_counter()
+                nxt = next(it, None)                                       # (the loader's wait: decode + upload of frame t + 1 not ready yet)
+                b = time.perf_counter()
+                if ahead_mode:
+                    pbl_det = model.PersonDetectResult(ticket) if ticket is not None else model.PersonDetect(imagelist, t)
+                    ticket = model.PersonDetectAhead(nxt[1], nxt[0]) if nxt is not None else None
+                else:
+                    pbl_det = model.PersonDetect(imagelist, t)
+                c = time.perf_counter()
+                vl, bx = boxes[t]
+                pbl = [[] for _ in range(C)]
+                for v, bb in zip(vl, bx):
+                    pbl[v].append(dict(image_id=t, category_id=1, score=0.9, bbox=bb, data=imagelist[v], feature=[]))
+                dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=max(20, len(vl)))
+                dump.device_det.copy_(det_dev[t]); dump.poses_host = det_host[t]
+                d = time.perf_counter()
+                r = model.PersonTrack_Project3DPose(t, pbl, dump, 'SVD')
+                e = time.perf_counter()
+                tl += b - a; td += c - b; tp += d - c; tt += e - d
+                emitted += len(r[5]) if k >= W else 0
+                cur = nxt; k += 1
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t_start
+            loader.close()
+            st = {'loader_wait': tl / K, 'detect': td / K, 'pose': tp / K, 'track': tt / K}
+            return {'value': K / el, 'ms_per_frame': el / K * 1e3, 's_per_frame_by_stage': st, 'bound_by': max(st, key=st.get),
+                    # the reference's own two print-outs from the same stage times (testmodel.py:92-98; its fps divides detect + pose by the views)
+                    'reference_formula_fps': 1.0 / max(1e-12, (st['detect'] + st['pose']) / C + st['track']), 'emitted_poses': emitted}
+        mode0, pipe.net.flag_race = pipe.net.flag_race, 'serial'
+        try:
+            serial = run(False)
+            ahead = run(True)
+        finally:
+            pipe.net.flag_race = mode0
+        return {'value': ahead['value'], 'unit': 'frames/s', 'steps': K, 'warmup': W, 'serial': serial, 'ahead': ahead,
+                'loader_alone_frame_sets_per_s': loader_alone, 'loader_workers': workers, 'host_cores_usable': usable,
+                'jpeg_bytes_per_frame_set': jpeg_bytes, 'views': C, 'image': '%dx%d' % (fw, fh),
+                'what': 'JPEG files -> FrameLoader -> PersonDetect -> PersonPoseDetect -> PersonTrack_Project3DPose as pam/testmodel.py drives them; '
+                        '`value` = the detect-ahead order (its default), wall clock over K frames incl. the 9-tuple on the host every frame'}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def ab_vs_previous_round(torch, hrnet_mod, net, n, dev, rounds=7, iters=20):
+    """The round's executor against the previous round's, INTERLEAVED in this process on this device (a 9 % box-to-box spread can neither
+    hide nor invent a step): the n-crop forward as this build replays it (throughput form: replays back to back) vs a second executor
+    object over the same weights set back to round 4's switches -- branch streams joined by stream events, fuse-layer sums as separate
+    launches with merged 1x1 products, strided 3x3 layers on the generic kernels.  Medians over `rounds` rounds of `iters` replays."""
+    prev = hrnet_mod.HRNetPose(48, 17, None, resolution=(384, 288), device=dev.index, use_graph=True, autotune=False,
+                               max_dets=net.max_dets, max_crops=max(n, 1))
+    prev.hip.flag_sync = False
+    prev.hip.down48 = False
+    prev.hip.down_s = False
+    prev.flag_race = None
+    x0, x1 = net.input_buffer(n), prev.input_buffer(n)
+    x1.copy_(x0)
+    race0, net.flag_race = net.flag_race, 'throughput'
+    try:
+        for _ in range(3):
+            net.features(x0); prev.features(x1)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(net.features(x0)[:, :, :8], net.features(x0)[:, :, :8]))
+        ta, tb = [], []
+        for _ in range(rounds):
+            for fn, x, acc in ((net.features, x0, ta), (prev.features, x1, tb)):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    fn(x)
+                e1.record(); torch.cuda.synchronize()
+                acc.append(e0.elapsed_time(e1) / iters)
+    finally:
+        net.flag_race = race0
+    a, b = float(np.median(ta)), float(np.median(tb))
+    return {'ms_default': a, 'ms_previous': b, 'ratio': a / b, 'crops': n, 'rounds': rounds, 'replays_per_round': iters,
+            'default': {'config': net.config_for(n), 'branch_sync': 'flags' if net.flag_synced.get((n, 'features', 0)) else 'events'},
+            'previous': 'round-4 executor: PAM_FLAG_SYNC=0 (stream events), fused_sums=0, down48=down_s=0, configuration fused48_fused96',
+            'deterministic': same, 'spread_default': [float(min(ta)), float(max(ta))], 'spread_previous': [float(min(tb)), float(max(tb))]}
 
 
 def batched_tracker(torch, synth, cams, cfg, conf, size, B, dev, n_frames=40, distinct=8):

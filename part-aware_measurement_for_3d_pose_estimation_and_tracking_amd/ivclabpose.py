@@ -148,8 +148,26 @@ class ivclabpose(object):
         """ivclabpose.py:183-204: per image a list of person dicts, boxes clamped to the image, xywh."""
         if self.person_detector is None or _cfg(self.person_detector, 'NAME') != 'YOLOv3':
             return None
+        return self._person_dicts(imglist, image_id, self.bbox_detector(imglist))
+
+    def PersonDetectAhead(self, imglist, image_id):
+        """Not in the reference: PersonDetect split in two so that a driver which already holds the NEXT frame's images (the loader decodes
+        ahead) can run that frame's detector under the current frame's pose network -- issue here (a stream of its own, nothing waits),
+        collect with ``PersonDetectResult``.  Same boxes as PersonDetect (same replay, same decode)."""
+        if self.person_detector is None or _cfg(self.person_detector, 'NAME') != 'YOLOv3':
+            return None
+        if getattr(self, '_det_stream', None) is None:
+            self._det_stream = torch.cuda.Stream(self.bbox_detector.device)
+        return (imglist, image_id, self.bbox_detector.submit(imglist, stream=self._det_stream))
+
+    def PersonDetectResult(self, ahead):
+        if ahead is None:
+            return None
+        imglist, image_id, ticket = ahead
+        return self._person_dicts(imglist, image_id, self.bbox_detector.collect(ticket))
+
+    def _person_dicts(self, imglist, image_id, results):
         person_bbox_list = []
-        results = self.bbox_detector(imglist)
         for idx, result in enumerate(results):
             h, w = imglist[idx].shape[:2]
             person_temps = []

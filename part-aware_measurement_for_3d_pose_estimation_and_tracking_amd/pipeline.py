@@ -229,6 +229,8 @@ class FramePipeline(object):
     def pose_step(self, frame_ptrs, view_local, slot_of, boxes, time_events=None, after_crop=None):
         """HRNet side for this rank's crops.  view_local: int32 (N,) index into self.mine; writes self.det_local."""
         if int(view_local.numel()) == 0 or self.net is None:
+            if after_crop is not None:
+                after_crop()
             return
         self._pose(frame_ptrs, view_local, slot_of, boxes, self.det_local, time_events, after_crop)
 
@@ -275,6 +277,8 @@ class FramePipeline(object):
         """HRNet side for this rank's share of the frame's crops; view_of indexes ALL views (frame_ptrs has C entries).
         Decodes straight into the exchange buffer at (view, slot)."""
         if int(view_of.numel()) == 0 or self.net is None:
+            if after_crop is not None:
+                after_crop()                             # (a feeder's release / the next frame's detection are due on empty frames too)
             return
         self._pose(frame_ptrs, view_of, slot_of, boxes, self.crop_gather.send, time_events, after_crop)
 

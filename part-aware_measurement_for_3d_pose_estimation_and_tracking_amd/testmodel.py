@@ -31,12 +31,17 @@ def build_model(cfg):
                       conf_threshold=pipe['CONF_THRESHOLD']), pipe['BUILD_3D']
 
 
-def frame_inputs(model, precomputed, frame_id, imagelist):
-    """person_bbox_list + dump_result_list for one frame -> (pbl, dump, detect seconds, pose seconds)."""
+def frame_inputs(model, precomputed, frame_id, imagelist, ahead=None, next_frame=None):
+    """person_bbox_list + dump_result_list for one frame -> (pbl, dump, detect seconds, pose seconds, the next frame's detection ticket).
+    ahead: this frame's detection, issued one frame ago (PersonDetectAhead); next_frame = (frame_id, imagelist) of the frame after this
+    one when the loader has it already: its detection is issued BEFORE this frame's pose network and runs under it."""
     dt_det = 0.0
+    nxt = None
     if model.person_detector is not None:                    # testmodel.py:56-58
         t0 = time.time()
-        pbl = model.PersonDetect(imagelist, frame_id)
+        pbl = model.PersonDetectResult(ahead) if ahead is not None else model.PersonDetect(imagelist, frame_id)
+        if next_frame is not None:
+            nxt = model.PersonDetectAhead(next_frame[1], next_frame[0])
         dt_det = time.time() - t0
     else:
         views = precomputed.get(frame_id, [[] for _ in imagelist])
@@ -45,10 +50,10 @@ def frame_inputs(model, precomputed, frame_id, imagelist):
         if all('keypoints' in p for persons in views for p in persons):
             dump = [[dict(bbox=list(p['bbox']), keypoints=list(p['keypoints']), keypoints_score=list(p['keypoints_score']),
                           feature=[]) for p in persons] for persons in views]
-            return pbl, dump, 0.0, 0.0
+            return pbl, dump, 0.0, 0.0, None
     t0 = time.time()
     dump = model.PersonPoseDetect(imagelist=None, person_bbox_list=pbl, batch_size=20)
-    return pbl, dump, dt_det, time.time() - t0
+    return pbl, dump, dt_det, time.time() - t0, nxt
 
 
 def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
@@ -64,11 +69,27 @@ def test_ivclabpose_PersonTrack_Project3DPose(cfg, inputs, on_frame=None):
     t_det = t_pose = t_track = 0.0
     start, end = dataset.TEST_RANGE
     n_views = len(dataset.FOLDERS_ORDER)
-    loader = FrameLoader(dataset.TEST_DATASET, inputs, indices=range(start, end), workers=int(dataset.get('LOADER_THREADS', 8)))
-    for i, (frame_id, imagelist, timestamp) in enumerate(loader):     # decoded a few frames ahead on worker threads
+    # images are decoded a few frames ahead on worker threads; with a GPU pipeline behind them (detector or pose network) they are
+    # uploaded from pinned memory on a copy stream and arrive as CUDA tensors (LOADER_DEVICE: false keeps them NumPy arrays, which
+    # the overlay needs anyway).  DETECT_AHEAD (default on): frame t + 1's person detection is issued before frame t's pose network.
+    draw = bool(cfg.get('VISUALIZATION') or cfg.get('SAVE_IMAGE'))
+    on_gpu = (model.person_detector is not None or model.pose_model is not None) and not draw and bool(dataset.get('LOADER_DEVICE', True))
+    look_ahead = model.person_detector is not None and bool(dataset.get('DETECT_AHEAD', True))
+    loader = FrameLoader(dataset.TEST_DATASET, inputs, indices=range(start, end), workers=int(dataset.get('LOADER_THREADS', 8)),
+                         device=(model.device if on_gpu else None))
+    it = iter(loader)
+    cur = next(it, None)
+    ahead = None
+    i = -1
+    while cur is not None:
+        i += 1
+        frame_id, imagelist, timestamp = cur
+        nxt_frame = next(it, None)
         if i == 0:
             model.GetCameraParameters(camera_parameter, imagelist[0].shape[0], imagelist[0].shape[1])
-        pbl, dump, dt_det, dt_pose = frame_inputs(model, precomputed, frame_id, imagelist)
+        pbl, dump, dt_det, dt_pose, ahead = frame_inputs(model, precomputed, frame_id, imagelist, ahead,
+                                                         (nxt_frame[0], nxt_frame[1]) if (look_ahead and nxt_frame is not None) else None)
+        cur = nxt_frame
         result = None
         dt_track = 0.0
         if any(len(v) for v in dump):                       # testmodel.py:66 guard: no pose in any view -> frame skipped

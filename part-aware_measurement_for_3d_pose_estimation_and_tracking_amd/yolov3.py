@@ -364,6 +364,7 @@ class YOLOv3(object):
         self.use_graph = use_graph
         self._graphs, self._pool = {}, None
         self._det_ws = {}            # views per call -> workspace of pam_yolo_detect_ws (zeroed once; the kernel leaves its tickets zero)
+        self._pinned = {}            # (views, fh, fw) -> two pinned (boxes, count) landing buffers of submit()
 
     # -- device path ---------------------------------------------------------------------------------------------------------
     def _run(self, ptrs, n, fh, fw, x8, boxes, count):
@@ -432,23 +433,56 @@ class YOLOv3(object):
         g = self._graphs.get((n, fh, fw))
         return g[1] if g is not None else torch.empty((n, fh, fw, 3), dtype=torch.uint8, device=self.device)
 
-    def __call__(self, imglist):
+    def submit(self, imglist, stream=None):
+        """Issue the detection of imglist (BGR uint8 HxWx3 arrays or CUDA tensors) WITHOUT waiting for it: frames into the replay's input,
+        one replay per image shape, the boxes' copy to pinned host memory, one event -- all on `stream` (default: the current one).
+        -> a ticket for ``collect``.  The reference's loop is detect -> pose -> track (/root/reference/src/testmodel.py:56-63); a driver
+        that has the next frame's images early (the loader decodes ahead) submits frame t + 1 here before it runs frame t's pose network,
+        and the detector runs under it (ivclabpose.PersonDetectAhead)."""
         single = isinstance(imglist, np.ndarray) and imglist.ndim == 3
         imgs = [imglist] if single else list(imglist)
-        results = [None] * len(imgs)
         by_shape = {}
         for i, im in enumerate(imgs):
             by_shape.setdefault(tuple(im.shape[:2]), []).append(i)
-        for (fh, fw), idx in by_shape.items():
-            buf = self.frame_buffer(len(idx), fh, fw)
-            for k, i in enumerate(idx):
-                im = imgs[i]
-                buf[k].copy_(im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im)), non_blocking=True)
-            boxes, count = self.detect_dev(buf)
-            boxes, count = boxes.cpu().numpy(), count.cpu().numpy()
+        cur = torch.cuda.current_stream(self.device)
+        st = stream if stream is not None else cur
+        parts = []
+        self._tick = getattr(self, '_tick', 0) + 1
+        with torch.cuda.stream(st):
+            if st is not cur:
+                st.wait_stream(cur)                      # the images were produced / uploaded on the caller's stream
+            for (fh, fw), idx in by_shape.items():
+                buf = self.frame_buffer(len(idx), fh, fw)
+                for k, i in enumerate(idx):
+                    im = imgs[i]
+                    if torch.is_tensor(im):
+                        im.record_stream(st)
+                    buf[k].copy_(im if torch.is_tensor(im) else torch.from_numpy(np.ascontiguousarray(im)), non_blocking=True)
+                boxes, count = self.detect_dev(buf)
+                # two pinned landing buffers per (views, shape), used alternately: a ticket stays readable while the next one is in flight
+                pin = self._pinned.setdefault((len(idx), fh, fw), [None, None])
+                k2 = self._tick & 1
+                if pin[k2] is None:
+                    pin[k2] = (torch.empty(boxes.shape, dtype=boxes.dtype).pin_memory(), torch.empty(count.shape, dtype=count.dtype).pin_memory())
+                pin[k2][0].copy_(boxes, non_blocking=True); pin[k2][1].copy_(count, non_blocking=True)
+                parts.append((idx, pin[k2]))
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return (single, len(imgs), parts, ev)
+
+    def collect(self, ticket):
+        """Wait for a ``submit`` and unpack it: one (k, 5) float32 array per image, rows (x1, y1, x2, y2, score), best score first."""
+        single, n, parts, ev = ticket
+        ev.synchronize()
+        results = [None] * n
+        for idx, (boxes, count) in parts:
+            boxes, count = boxes.numpy(), count.numpy()
             for k, i in enumerate(idx):
                 if count[len(idx) + k] > _lib.YOLO_MAX_CAND:    # only the first YOLO_MAX_CAND (coarse head first) entered the NMS
                     warnings.warn('image %d: %d boxes above score_thresh=%g, NMS capacity is %d -- raise the threshold' %
                                   (i, count[len(idx) + k], self.score_thresh, _lib.YOLO_MAX_CAND))
                 results[i] = boxes[k, :count[k]].copy()
         return results[0] if single else results
+
+    def __call__(self, imglist):
+        return self.collect(self.submit(imglist))
