@@ -219,6 +219,14 @@ __global__ __launch_bounds__(512) void k_bblock2_48(BB2Args a) {
     // addressed BEFORE the barrier (a wave that finished early does this beside its SIMD partner's MFMAs), written after it
     uint32_t mid[MW1][6];
     int maddr[MW1];
+#ifdef PAM_KO_SERIAL                                       // timing knock-out (WRONG results): what the serial phases between and after the two
+    // K loops cost -- the intermediate is neither packed nor written (conv2 multiplies whatever X holds), no barriers, no residual, one
+    // store per lane instead of the epilogue.  The bound of any scheme that hides these phases behind another item's MFMAs.
+#pragma unroll
+    for (int i = 0; i < MW1; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[i][j]));
+#else
 #pragma unroll
     for (int i = 0; i < MW1; ++i) {
         const int p = (wave + 8 * i) * 16 + l15;
@@ -243,6 +251,7 @@ __global__ __launch_bounds__(512) void k_bblock2_48(BB2Args a) {
         *(u32x2*)(d + 64 + 8 * g) = (u32x2){mid[i][4], mid[i][5]};
     }
     __syncthreads();                                     // the intermediate is visible
+#endif
     BB2_STAMP(5);
 
     // ---- conv2 + epilogue ------------------------------------------------------------------------------------------------------------
@@ -273,6 +282,18 @@ __global__ __launch_bounds__(512) void k_bblock2_48(BB2Args a) {
     else if (mt2 == 3) conv_pass<3>(acc, wl + WIMG, xl, koff, top2);
     else conv_pass<2>(acc, wl + WIMG, xl, koff, top2);
     BB2_STAMP(6);
+#ifdef PAM_KO_SERIAL
+    {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MW2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { asm volatile("" ::"v"(acc[i][j])); sum += acc[i][j][0]; }
+        if (ooff[0] >= 0) a.out[ooff[0]] = (uint16_t)(__builtin_bit_cast(uint32_t, sum) >> 16);
+        (void)rq; (void)rh;
+        return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < MW2; ++i) {
         if (ooff[i] < 0) continue;

@@ -133,6 +133,96 @@ __device__ inline int lsap_solve(int nr0, int nc0, const double* cost, int ld, d
     return n;
 }
 
+// The same algorithm run by ONE WAVE (round 6): lane j keeps column j's state (v, shortest path cost, predecessor, assigned row, position
+// in the `remaining` list), lane i row i's (u, assigned column, visited flag); every step of the shortest-augmenting-path search is one
+// parallel relaxation of all remaining columns + wave reductions instead of a lane walking the list through LDS (11.6 us per frame for
+// the five 4 x 4 problems of a Shelf frame, 33 us for the 31-camera rig's, all in dependent LDS round trips).  Results are the serial
+// solver's bit for bit: the relaxations are the same expressions, and its tie rule -- walking `remaining` in list order, a column
+// replaces the running minimum when strictly lower, or equal AND unassigned -- means: the LAST unassigned minimal column in list order
+// if there is one, else the FIRST minimal column; list order is kept per lane (`pos`; removal moves the last entry into the hole).
+// All 64 lanes must call it (max(nr0, nc0) <= 64); lane L < returned n holds pair (row, col) L of the row-sorted result.
+__device__ inline int lsap_solve_wave(int nr0, int nc0, const double* cost, int ld, double sign, int* rows_out, int* cols_out,
+                                      int& my_row, int& my_col) {
+    const int lane = threadIdx.x & 63;
+    my_row = my_col = -1;
+    if (nr0 == 0 || nc0 == 0) return 0;
+    const bool tr = nc0 < nr0;
+    const int nr = tr ? nc0 : nr0, nc = tr ? nr0 : nc0;
+    int width = 1;
+    while (width < nc) width <<= 1;                      // the reductions run over the lanes that can hold a column
+    const double INF = __builtin_huge_val();
+    double u = 0.0, v = 0.0, spc = INF;
+    int col4row = -1, row4col = -1, path = -1, pos = -1;
+    for (int cur = 0; cur < nr; ++cur) {
+        spc = INF;
+        pos = lane < nc ? nc - 1 - lane : -1;            // remaining[it] = nc - 1 - it
+        bool SR = false, SC = false;
+        int num_rem = nc, i = cur, sink = -1;
+        double min_val = 0.0;
+        while (sink == -1) {
+            if (lane == i) SR = true;
+            const double ui = __shfl(u, i);
+            const bool active = pos >= 0;
+            double sp = spc;
+            if (active) {
+                const double c = sign * (tr ? cost[(size_t)lane * ld + i] : cost[(size_t)i * ld + lane]);
+                const double r = min_val + c - ui - v;
+                if (r < sp) { path = i; spc = r; sp = r; }
+            }
+            double lowest = active ? sp : INF;
+            for (int m = 1; m < width; m <<= 1) { const double o = __shfl_xor(lowest, m); lowest = o < lowest ? o : lowest; }
+            if (lowest == INF) return -1;
+            const bool ismin = active && sp == lowest;
+            const bool unas = ismin && row4col == -1;
+            const bool anyun = __ballot(unas) != 0ull;
+            // the chosen list position: max over the unassigned minima, else min over the minima
+            int key = anyun ? (unas ? pos : -1) : (ismin ? pos : 0x7fffffff);
+            for (int m = 1; m < width; m <<= 1) { const int o = __shfl_xor(key, m); key = anyun ? (o > key ? o : key) : (o < key ? o : key); }
+            const int jsel = __ffsll((long long)__ballot(active && pos == key)) - 1;
+            min_val = lowest;
+            const int r4c = __shfl(row4col, jsel);
+            if (r4c == -1) sink = jsel; else i = r4c;
+            --num_rem;                                   // remaining[index] = remaining[--num_rem]
+            if (lane == jsel) { SC = true; pos = -1; }
+            else if (pos == num_rem) pos = key;
+        }
+        // dual update (the row / column roles of a lane are separate variables)
+        const double spc_of_mine = __shfl(spc, col4row >= 0 ? col4row : 0);
+        if (lane == cur) u += min_val;
+        else if (lane < nr && SR) u += min_val - spc_of_mine;
+        if (SC) v -= min_val - spc;
+        // augment along the predecessor chain
+        int j = sink;
+        for (;;) {
+            const int ii = __shfl(path, j);
+            if (lane == j) row4col = ii;
+            const int t = __shfl(col4row, ii);
+            if (lane == ii) col4row = j;
+            j = t;
+            if (ii == cur) break;
+        }
+    }
+    int n;
+    if (tr) {                                            // solved rows are original columns; emit sorted by original row
+        const bool has = lane < nc && row4col != -1;
+        const unsigned long long b = __ballot(has);
+        n = __popcll(b);
+        const int at = __popcll(b & ((1ull << lane) - 1ull));
+        if (has) { rows_out[at] = lane; cols_out[at] = row4col; }
+        // lane L < n holds pair L: fetch it from the lane that owns it
+        unsigned long long bb = b;
+        int owner = -1;
+        for (int q = 0; q <= lane && bb; ++q) { owner = __ffsll((long long)bb) - 1; bb &= bb - 1; if (q == lane) break; owner = -1; }
+        const int src = owner >= 0 ? owner : 0;
+        const int rc = __shfl(row4col, src);
+        if (lane < n) { my_row = src; my_col = rc; }
+    } else {
+        n = nr;
+        if (lane < nr) { rows_out[lane] = lane; cols_out[lane] = col4row; my_row = lane; my_col = col4row; }
+    }
+    return n;
+}
+
 // ---- a7: epipolar point-to-line distance, vectorised ("parallel") form, matching.py:115-151 ---------------------
 // distance of point j to the line induced in its view by point i:  l = F[ci][cj]^T (xi, yi, 1)
 __device__ __forceinline__ double epi_directed(const float* __restrict__ Fij, double xi, double yi, double xj, double yj) {

@@ -163,11 +163,17 @@ __device__ __forceinline__ double now_s() { return (double)__builtin_amdgcn_s_me
 // The per-frame step: IterativeTracker.tracking (IterativeTracker.py:115-180) + output collection
 // (ivclabpose.py:259-287).  One 256-thread workgroup per scene; phases separated by workgroup barriers.
 // =====================================================================================================================
-template <int NTHREADS>
+// PART: 0 = the whole step in one launch.  Rigs with more than 8 cameras run it as THREE launches (round 6): 1 = P0-P4a (association,
+// view selection), 2 = P4b (the epipolar conflict sets: nT x V(V-1)/2 x 17 independent items -- 55 000 on the 31-camera rig, which one
+// workgroup walked in 54 passes of dependent L2 loads, 136 of its 297 us) spread over MANY workgroups, 3 = P4c-P7.  The split forms keep
+// all scratch and the integer state in global memory (hot_in_lds = 0); one scene per handle.
+template <int NTHREADS, int PART = 0>
 __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
     const Dims d = A.d;
     const int C = d.C, MAXP = d.MAXP, MAXT = d.MAXT, HCAP = d.HCAP, MAXH = d.MAXH;
-    const int sidx = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    const int sidx = PART == 2 ? 0 : blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    // P4b's items are dealt over the whole grid in the split form
+    const int it0 = PART == 2 ? (int)blockIdx.x * (int)blockDim.x + tid : tid, itS = PART == 2 ? (int)(gridDim.x * blockDim.x) : NT;
     SceneState st; Scratch ws;
     carve_state(A.state + (size_t)sidx * A.state_stride, d, st);
     carve_ws(A.ws + (size_t)sidx * A.ws_stride, d, ws);
@@ -179,10 +185,13 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
     //      out a frame it later disowns.  The word is raised on THIS device (A.guard) or travels with a view-sharded record (second double
     //      of its count row, set by the rank that produced it).  A void frame leaves the state as it is; hdr[6] remembers the first frame
     //      of the current run of void frames (+ 1) so that the host knows where to resume.
-    {
+    if (PART >= 2) {                                     // the split step decides ONCE, in its first launch (the word may rise between the launches)
+        if (ws.misc[2]) return;
+    } else {
         int voided = A.guard ? __hip_atomic_load(A.guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         if (A.view_row)
             for (int v = 0; v < d.C; ++v) voided |= (A.det[((size_t)A.view_row[v] * (d.MAXP + 1) + d.MAXP) * J3 + 1] != 0.0);
+        if (PART == 1 && threadIdx.x == 0) ws.misc[2] = voided;
         if (voided) {
             if (threadIdx.x == 0) {
                 int* oi = A.out_i + (size_t)sidx * A.ol.int_words;
@@ -195,16 +204,20 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
             return;
         }
     }
+    char* const ws_glob = A.ws + (size_t)sidx * A.ws_stride;         // the hot scratch's home in global memory (between the launches of a split step)
     if (A.hot_in_lds) {
         carve_ws_hot(hot_lds, d, ws);                                   // small scratch in LDS
         char* st_lds = hot_lds + hot_bytes(d);                          // integer scene state in LDS for this frame
         for (size_t o = (size_t)threadIdx.x * 4; o < st_ints; o += (size_t)blockDim.x * 4) *(int*)(st_lds + o) = *(const int*)(st_glob + o);
+        if (PART == 3)                                                  // ... and what the first two launches left in the hot scratch
+            for (size_t o = (size_t)threadIdx.x * 4; o < hot_bytes(d); o += (size_t)blockDim.x * 4) *(int*)(hot_lds + o) = *(const int*)(ws_glob + o);
         const ptrdiff_t sh = st_lds - st_glob;
 #define REBASE(p) p = (int*)((char*)(p) + sh)
         REBASE(st.hdr); REBASE(st.order); REBASE(st.track_id); REBASE(st.hits); REBASE(st.age); REBASE(st.tsu); REBASE(st.already);
         REBASE(st.state); REBASE(st.p2d_n); REBASE(st.h_head); REBASE(st.h_len); REBASE(st.jv_V); REBASE(st.p2d_order);
         REBASE(st.p2d_time); REBASE(st.cur_det); REBASE(st.hist_time); REBASE(st.jv_count);
 #undef REBASE
+        if (PART == 1 && threadIdx.x == 0) ws.misc[2] = 0;               // (the LDS copy goes home at the end of this launch: not void, see above)
         __syncthreads();
     }
     const PamParams& prm = *A.prm;
@@ -230,6 +243,7 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
     // device-side counts are not validated by the host (pam_frame_dev): clamp them so that no index leaves det / ws.taken
 #define NDET(v) min(max(NDET_RAW(v), 0), MAXP)
 
+    if (PART <= 1) {
     // ---- P0: add_age, time gaps (IterativeTracker.py:126-129) -------------------------------------------------------
     if (tid == 0) {
         out_d[0] = now_s(); ws.misc[1] = nT;
@@ -262,24 +276,30 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
                                prm.alpha2d * (double)dt, e, prm.count_gate);
     }
     __syncthreads();
+#ifdef PAM_FINE_STAMPS
+    if (tid == 0) out_d[12] = now_s();
+#endif
 
     // ---- P2: one assignment problem per view (:150-160) ---------------------------------------------------------
-    for (int v = tid; v < C; v += NT) {
+    // one WAVE per view (lsap_solve_wave: a lane per column / row), views dealt over the workgroup's waves
+    for (int v = tid >> 6; v < C; v += NT >> 6) {
         const int m = NDET(v);
         if (nT > 0 && m > 0) {
-            LsapScratch sc = lsap_carve(ws.lsap1 + (size_t)v * ((lsap_scratch_bytes(d.N1) + 7) & ~(size_t)7), d.N1);
             int* rows = ws.as_rows + v * d.N1; int* cols = ws.as_cols + v * d.N1;
             const double* aff = ws.aff + (size_t)v * MAXT * MAXP;
-            const int np = lsap_solve(nT, m, aff, MAXP, -1.0, sc, rows, cols);
-            if (np < 0) atomicOr(&st.hdr[2], ST_LSAP_INFEASIBLE);
-            for (int k = 0; k < np; ++k)
-                if (aff[rows[k] * MAXP + cols[k]] > 0.0) {
-                    ws.match_det[rows[k] * C + v] = cols[k];
-                    ws.taken[v * MAXP + cols[k]] = 1;
-                }
+            int row, col;
+            const int np = lsap_solve_wave(nT, m, aff, MAXP, -1.0, rows, cols, row, col);
+            if (np < 0 && (tid & 63) == 0) atomicOr(&st.hdr[2], ST_LSAP_INFEASIBLE);
+            if ((tid & 63) < np && aff[row * MAXP + col] > 0.0) {
+                ws.match_det[row * C + v] = col;
+                ws.taken[v * MAXP + col] = 1;
+            }
         }
     }
     __syncthreads();
+#ifdef PAM_FINE_STAMPS
+    if (tid == 0) out_d[13] = now_s();
+#endif
 
     // ---- P3: add_pose (:155-160,289-298), unmatched lists + confidence filter (:56-61,163-167) ----------------
     for (int i = tid; i < nT; i += NT) {
@@ -329,15 +349,27 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
     __syncthreads();
 
     if (tid == 0) out_d[4] = now_s();
+    }                                                    // PART <= 1
+    if (PART == 1) {                                     // hand over: hot scratch and integer state back to global memory
+        if (A.hot_in_lds) {
+            const char* st_lds = hot_lds + hot_bytes(d);
+            for (size_t o = (size_t)threadIdx.x * 4; o < hot_bytes(d); o += (size_t)blockDim.x * 4) *(int*)(ws_glob + o) = *(const int*)(hot_lds + o);
+            for (size_t o = (size_t)threadIdx.x * 4; o < st_ints; o += (size_t)blockDim.x * 4) *(int*)(st_glob + o) = *(const int*)(st_lds + o);
+        }
+        if (tid == 0) out_d[15] = now_s();               // split step: end of launch 1 / [12], [13] launch 2's first workgroup / [14] start of launch 3
+        return;
+    }
+    if (PART == 2 && blockIdx.x == 0 && tid == 0) out_d[12] = now_s();
+    if (PART == 3 && tid == 0) out_d[14] = now_s();
     // ---- P4b: per-joint conflict sets of the part-aware filter (matching.py:115-151, IterativeTracker.py:345-346): one
     //           lane per (track, joint, view pair r < c), bits OR-ed into the row masks; back-projection ray distances
     //           (matching.py:254-270) one lane per (track, joint, view) ---------------------------------------------------
     int maxV = 0;
     for (int i = 0; i < nT; ++i) maxV = max(maxV, ws.sel_n[i]);
-    {
+    if (PART != 3) {                                     // (launch 3 of the split step finds the conflict sets and ray distances done)
         const int npair = maxV * (maxV - 1) / 2;
         // joints fastest: the 17 lanes of one (track, view pair) share both fundamental matrices and read consecutive joints
-        for (int it = tid; it < nT * npair * J; it += NT) {
+        for (int it = it0; it < nT * npair * J; it += itS) {
             const int i = it / (npair * J), r2 = it % (npair * J), pq = r2 / J, j = r2 % J;
             const int V = ws.sel_n[i];
             // unrank pq -> (r, c), r < c < maxV (row-major over the strict upper triangle), closed form
@@ -353,13 +385,17 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
                                         cc, st.p2d_pose + ((size_t)s * C + cc) * J3 + j * 3);
             if (1.0 - dsym / prm.joint_threshold < 0.0) atomicOr(&ws.conf[((size_t)i * J + j) * C + r], 1u << c);
         }
-        for (int it = tid; it < nT * J * C; it += NT) {
+        for (int it = it0; it < nT * J * C; it += itS) {
             const int i = it / (J * C), r2 = it % (J * C), j = r2 / C, r = r2 % C;
             if (r >= ws.sel_n[i]) continue;
             const int s = st.order[i], cr = ws.sel_cid[i * C + r];
             const double* pr = st.p2d_pose + ((size_t)s * C + cr) * J3 + j * 3;
             ws.rayd[((size_t)i * J + j) * C + r] = ray_point_dist(cs.RKINV + cr * 9, cs.pos + cr * 3, pr[1], pr[0], ws.pred + i * J3 + j * 3);
         }
+    }
+    if (PART == 2) {
+        if (blockIdx.x == 0 && tid == 0) out_d[13] = now_s();
+        return;
     }
     __syncthreads();
 
@@ -705,7 +741,12 @@ __global__ void k_op_affinity(CamSet cs, const PamParams* prm, int cid, int n, i
     }
 }
 __global__ void k_op_lsap(int nr, int nc, const double* cost, char* scratch, int N, int* rows, int* cols, int* np) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // one wave: the solver the frame kernel runs per view (N <= 64); beyond that the single-lane form the hypothesis step uses
+    if (N <= 64) {
+        int row, col;
+        const int n = lsap_solve_wave(nr, nc, cost, nc, 1.0, rows, cols, row, col);
+        if (threadIdx.x == 0) *np = n;
+    } else if (threadIdx.x == 0) {
         LsapScratch sc = lsap_carve(scratch, N);
         *np = lsap_solve(nr, nc, cost, nc, 1.0, sc, rows, cols);
     }
@@ -947,7 +988,19 @@ static int launch_frame(PamHandle* h, hipStream_t s, int frame_id, const int* d_
     if (dblock == 64) { hipLaunchKernelGGL(k_frame<64>, dim3(h->d.S), dim3(64), A.hot_in_lds ? hot : 0, s, A); HIPCHK(h, hipGetLastError()); return PAM_OK; }
     if (dblock == 128) { hipLaunchKernelGGL(k_frame<128>, dim3(h->d.S), dim3(128), A.hot_in_lds ? hot : 0, s, A); HIPCHK(h, hipGetLastError()); return PAM_OK; }
 #endif
-    if (block == 1024) hipLaunchKernelGGL(k_frame<1024>, dim3(h->d.S), dim3(1024), A.hot_in_lds ? hot : 0, s, A);
+    // wide rigs, one scene: three launches, the conflict sets of P4b over the whole chip (PAM_FRAME_SPLIT=0: the single launch, for A/B runs)
+    static const int split_ok = getenv("PAM_FRAME_SPLIT") ? atoi(getenv("PAM_FRAME_SPLIT")) : 1;
+    if (block == 1024 && h->d.S == 1 && split_ok) {
+        // launches 1 and 3 keep the hot scratch and the integer state in LDS (the serial LSAP walks live there) and hand them over through
+        // their home in global memory; launch 2 works on the global copy
+        const int in_lds = A.hot_in_lds;
+        hipLaunchKernelGGL((k_frame<1024, 1>), dim3(1), dim3(1024), in_lds ? hot : 0, s, A);
+        A.hot_in_lds = 0;
+        hipLaunchKernelGGL((k_frame<256, 2>), dim3(256), dim3(256), 0, s, A);
+        A.hot_in_lds = in_lds;
+        hipLaunchKernelGGL((k_frame<1024, 3>), dim3(1), dim3(1024), in_lds ? hot : 0, s, A);
+    }
+    else if (block == 1024) hipLaunchKernelGGL(k_frame<1024>, dim3(h->d.S), dim3(1024), A.hot_in_lds ? hot : 0, s, A);
     else hipLaunchKernelGGL(k_frame<BLOCK>, dim3(h->d.S), dim3(BLOCK), A.hot_in_lds ? hot : 0, s, A);
     HIPCHK(h, hipGetLastError());
     return PAM_OK;

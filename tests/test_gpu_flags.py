@@ -67,7 +67,7 @@ def test_a_capture_whose_first_replay_times_out_is_replaced_by_stream_events():
     x.copy_(torch.randn(x.shape, generator=torch.Generator().manual_seed(9)).to(x.device).to(x.dtype)); x[:, 3:] = 0
     ref = a.features(x).clone()
     c = hrnet.HRNetPose(48, 17, None, use_graph=True)
-    c.hip.flag_max_us = 1
+    c.hip.set_flag_limit(1)
     y2 = c.features(x).clone()
     torch.cuda.synchronize()
     assert c.flag_synced[(5, 'features', 0)] is False and c.captures == 1 and len(c._dead_graphs) == 1 and torch.equal(ref, y2)

@@ -34,7 +34,7 @@ b.record(); torch.cuda.synchronize()
 us = a.elapsed_time(b) / args.iters * 1e3
 oi, od = h.fetch(st); h.sync(st)
 rec = h.decode(0)
-f = od[0][:12] * 1e6
+f = od[0][:16] * 1e6
 T = rec['n_tracks']; V = int(np.mean([t['V'] for t in rec['tracks']])) if T else 0
 P = synth.SIZES[args.size]['P']
 alg = C * P * 408 + T * ((11 + 2) * 408 + V * 408) + T * 408 + C * P * 4 + T * 68          # SURVEY 8d (same formula as bench.py)
@@ -46,5 +46,7 @@ phases = {'P0-P3 association (projection affinity, LSAP per view, add_pose, unma
 print(json.dumps({'workload': args.size, 'scenes': S, 'views': C, 'tracks': T, 'views_per_track': V, 'us_per_launch': us,
                   'algorithmic_bytes_per_scene': alg, 'algorithmic_GBs': alg * S / us / 1e3, 'status': rec['status'] | rec['status_sticky'],
                   'phase_us_scene0': {k: float(v) for k, v in phases.items()}, 'in_kernel_total_us_scene0': float(f[11] - f[0]),
-                  'block_threads': 1024 if C > 8 else 256}), flush=True)
+                  'block_threads': 1024 if C > 8 else 256,
+                  'fine_us': {'P0+P1': float(f[12] - f[0]), 'P2 lsap': float(f[13] - f[12]), 'P3': float(f[1] - f[13])} if os.environ.get('PAM_FINE') else None,
+                  'split_us': {'launch1_tail': float(f[15] - f[4]), 'gap_1_2': float(f[12] - f[15]), 'launch2_wg0': float(f[13] - f[12]), 'gap_2_3': float(f[14] - f[13]), 'launch3_prologue': float(f[5] - f[14])} if f[15] > 0 else None}), flush=True)
 h.close()
