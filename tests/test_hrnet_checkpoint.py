@@ -41,16 +41,17 @@ def test_checkpoint_file_round_trip(tmp_path):
     """A state dict saved in the official layout (also wrapped as {'model': ...}) loads through CHECKPOINT_FILE exactly as the YAML
     drives it, and the product path then computes with THOSE weights (same heat-maps as a module initialised from the same tensors)."""
     src = hrnet.init_random(hrnet.PoseHighResolutionNet(48, 17), seed=5)
+    b = hrnet.HRNetPose(48, 17, None, resolution=(384, 288), use_graph=False, seed=5)       # the same tensors, never through a file
+    c = hrnet.HRNetPose(48, 17, None, resolution=(384, 288), use_graph=False, seed=6)       # other weights
+    x = b.input_buffer(1)
+    x.copy_(torch.randn(x.shape, device=x.device).to(x.dtype)); x[:, 3:] = 0
+    yb, yc = b.heatmaps(x).clone(), c.heatmaps(x).clone()
     for wrap in (False, True):
         path = os.path.join(str(tmp_path), 'pose_hrnet_w48_384x288%s.pth' % ('_w' if wrap else ''))
         torch.save({'model': src.state_dict()} if wrap else src.state_dict(), path)
         a = hrnet.HRNetPose(48, 17, path, resolution=(384, 288), use_graph=False)
         assert a.weights == path
-        b = hrnet.HRNetPose(48, 17, None, resolution=(384, 288), use_graph=False, seed=5)
-        x = a.input_buffer(1)
-        x.copy_(torch.randn(x.shape, device=x.device).to(x.dtype)); x[:, 3:] = 0
-        ya, yb = a.heatmaps(x), b.heatmaps(x)
+        ya = a.heatmaps(x)
         torch.cuda.synchronize()
         assert torch.equal(ya, yb)
-        c = hrnet.HRNetPose(48, 17, None, resolution=(384, 288), use_graph=False, seed=6)
-        assert not torch.equal(ya, c.heatmaps(x))
+        assert not torch.equal(ya, yc)
