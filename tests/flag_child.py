@@ -238,19 +238,19 @@ def section_pipeline(kill=19):
     print('PIPELINE-OK voids=%s' % voids, flush=True)
 
 
-def section_memory():
-    """What a prewarmed S2 pipeline holds with BOTH forms of every flagged bucket alive (the verdict's question): device memory before /
-    after, the activation arena, the number of captures."""
+def section_memory(size='S2'):
+    """What a prewarmed pipeline holds with BOTH forms of every flagged bucket alive (the verdict's question): device memory before /
+    after, the activation arena, the number of captures.  (`memory:S4` on the command line: the 31-camera rig, 62 buckets up to 248 crops.)"""
     from pam.pipeline import FramePipeline
-    seq, cams, cfg, conf, meta = _rig('S2')
+    seq, cams, cfg, conf, meta = _rig(size)
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
-    pipe = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=4, prewarm=True, overlap_tracker=True)
+    pipe = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=4 if size == 'S2' else 8, prewarm=True, overlap_tracker=True)
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     w = pipe.warmed
     both = sum(1 for a in pipe.net._alt.values() if a is not None)
-    print('MEMORY-OK buckets=%s captures=%d both_forms=%d arena_MB=%.1f device_MB=%.1f seconds=%.1f'
+    print('MEMORY-OK size=%s' % size, 'buckets=%s captures=%d both_forms=%d arena_MB=%.1f device_MB=%.1f seconds=%.1f'
           % (w['buckets'], w['captures'], both, w['arena_bytes'] / 2 ** 20, (free0 - free1) / 2 ** 20, w['seconds']), flush=True)
 
 
@@ -269,8 +269,9 @@ def main():
         section_surface(True)
     if 'pipeline' in want:
         section_pipeline()
-    if 'memory' in want:
-        section_memory()
+    for w in sorted(want):
+        if w.startswith('memory'):
+            section_memory(w.split(':')[1] if ':' in w else 'S2')
     print('CHILD-DONE', flush=True)
 
 

@@ -32,7 +32,8 @@ for name in ('S1_x1','S2_x1','S3_x1','S4_x1','S2_x2048'):
         for r in csv.DictReader(open(f)):
             if 'k_frame' not in r['Kernel_Name']: continue
             tot.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
-    c={k:(sum(v[-12:])/len(v[-12:])) for k,v in tot.items()}
+    # a frame of a wide rig is three k_frame launches (round 6): 32 frames per pass -> per FRAME means over the last 12 frames
+    c={k:(sum(v[-12*max(1,len(v)//32):])/12.0) for k,v in tot.items()}
     e=dict(plain); e['counters_per_launch']=c
     if 'FETCH_SIZE' in c and 'WRITE_SIZE' in c:
         # guide (HBM section): FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE reads HALF of a wide coalesced stream on gfx950.  k_frame's
