@@ -46,6 +46,27 @@ def section_flags(x, ref):
         assert len(d._dead_graphs) == 0 and set(d._alt[(5, 'features', 0)]) == {'flags', 'events'} and torch.equal(ref, yd)
         y1 = d.features(x, slot=1).clone(); torch.cuda.synchronize()
         assert torch.equal(ref, y1) and d.captures == 2
+    # the ordering assumption behind the flags: a signal's release covers the signalling wave only; that the stores of the
+    # kernels in front of it have left their XCD's L2 relies on the release the runtime puts at every kernel boundary of a graph chain.
+    # Asserted here on every run: for every crop-count bucket of the Shelf frame and every executor configuration the flagged replay
+    # and the stream-event replay of the same forward (both captured, both alive) give the same bits, five times over
+    from pam import hrnet_hip
+    for name in hrnet_hip.HipHRNet.CONFIGS:
+        e = hrnet.HRNetPose(48, 17, None, use_graph=True)
+        e.config_for = lambda n, name=name: name
+        e.flag_race = 'throughput'
+        for n in (4, 12, 20):
+            xn = e.input_buffer(n)
+            xn.copy_(torch.randn(xn.shape, generator=torch.Generator().manual_seed(n)).to(xn.device).to(xn.dtype)); xn[:, 3:] = 0
+            e.features(xn)
+            alt = e._alt[(n, 'features', 0)]
+            assert alt is not None and set(alt) == {'flags', 'events'}, (name, n, e.flag_synced)
+            for _ in range(5):
+                alt['flags'][0].replay(); yf = alt['flags'][2].clone()
+                alt['events'][0].replay(); ye = alt['events'][2].clone()
+                torch.cuda.synchronize()
+                assert torch.equal(yf, ye), (name, n)
+        assert int(e._flag_host_np[0]) == 0 and int(e.void_word.item()) == 0
     print('FLAGS-OK', flush=True)
     return b
 
