@@ -221,6 +221,33 @@ def test_persondetect_facade_format():
             assert isinstance(p['score'], float) and round(p['score'], 4) == p['score']
 
 
+def test_detection_a_frame_ahead_gives_persondetects_boxes():
+    """PersonDetectAhead / PersonDetectResult (not in the reference: PersonDetect split in two so that a driver can issue the next frame's
+    detection early): the same dicts as PersonDetect for the same images, also with a second ticket in flight before the first is
+    collected (two pinned landing buffers), for NumPy images and for CUDA tensors."""
+    import warnings
+    from pam import ivclabpose as IV, dataset
+    cfg = dataset.AttrDict(dict(NAME='YOLOv3', CFG=None, WEIGHT=None, CLASS_NAMES=None, SCORE_THRESH=0.5, NMS_THRESH=0.45))
+    api = IV.ivclabpose(person_detector=cfg, pose_detector=None, person_matcher=None)
+    rng = np.random.default_rng(11)
+    sets = [[rng.integers(0, 256, (240, 320, 3), dtype=np.uint8) for _ in range(3)] for _ in range(3)]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        want = [api.PersonDetect(imgs, image_id=k) for k, imgs in enumerate(sets)]
+        t0 = api.PersonDetectAhead(sets[0], 0)
+        got = []
+        for k in range(3):
+            nxt = api.PersonDetectAhead(sets[k + 1], k + 1) if k + 1 < 3 else None      # issued BEFORE frame k is collected
+            got.append(api.PersonDetectResult(t0))
+            t0 = nxt
+        dev = [torch.from_numpy(im).to('cuda:0') for im in sets[1]]
+        got_dev = api.PersonDetectResult(api.PersonDetectAhead(dev, 1))
+    strip = lambda frames: [[(p['image_id'], p['bbox'], p['score']) for p in v] for v in frames]
+    assert [strip(f) for f in got] == [strip(f) for f in want]
+    assert strip(got_dev) == strip(want[1]) and all(p['data'] is dev[v] for v, ps in enumerate(got_dev) for p in ps)
+    assert sum(len(v) for f in want for v in f) > 0
+
+
 def test_detect_then_pose_pipeline_runs():
     """DETECT_MODEL: YOLOv3 path of the driver: PersonDetect boxes feed PersonPoseDetect (random weights: shapes / plumbing only)."""
     import warnings
