@@ -386,6 +386,8 @@ int pam_fuse_sum_nhwc_bf16(void* stream, const void* base, int n_plain, const vo
  * by the host without touching the device; and dev_void, when given: a device word that receives 1, for consumers of the forward's
  * results on the device -- pam_set_input_guard; NULL = none).  Counters are zeroed by the caller in front of the first signal.  Flagged forwards of one process must not be in flight at the same time (their gates can block each other's queues). */
 int pam_flag_signal(void* stream, int32_t* dev_counter);
+/* the same add on every counter dev_counters[k] whose bit k of mask is set (k < 32), one launch, one release */
+int pam_flag_signal_mask(void* stream, int32_t* dev_counters, uint32_t mask);
 int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, const uint32_t* dev_max_us, int arrive, int32_t* host_err,
                   int32_t* dev_void);
 

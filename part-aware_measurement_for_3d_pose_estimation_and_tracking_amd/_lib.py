@@ -89,6 +89,7 @@ _SIGS = {
     'pam_conv3x3s2_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _P] + [_I] * 7),
     'pam_fuse_sum_nhwc_bf16': (_I, [_P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P] + [_I] * 8),
     'pam_flag_signal': (_I, [_P, _P]),
+    'pam_flag_signal_mask': (_I, [_P, _P, C.c_uint32]),
     'pam_flag_gate': (_I, [_P, _P, _I, _P, _P, _I, _P, _P]),
     'pam_set_input_guard': (_I, [_P, _P]),
     'pam_comm_unique_id': (_I, [_P]),

@@ -24,6 +24,18 @@ __global__ __launch_bounds__(64) void k_flag_signal(int* counter) {
     }
 }
 
+// several counters in one launch (round 6: one counter per OUTPUT of a module -- a sum waits for the branches' blocks and the chains it
+// reads, not for every branch's whole tail): lane k adds to counters[k] where bit k of mask is set; ONE release for all of them
+__global__ __launch_bounds__(64) void k_flag_signal_mask(int* counters, unsigned mask) {
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (threadIdx.x < 32 && ((mask >> threadIdx.x) & 1u))
+        __hip_atomic_fetch_add(counters + threadIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(64) void k_flag_gate(int* counter, int target, int* err, const unsigned* max_us_p, int arrive, int* host_err, int* dev_void) {
     if (threadIdx.x == 0) {
         if (arrive) {                                     // arrive-and-wait: this stream's own contribution, then everybody else's
@@ -52,6 +64,11 @@ __global__ __launch_bounds__(64) void k_flag_gate(int* counter, int target, int*
 extern "C" int pam_flag_signal(void* stream, int32_t* dev_counter) {
     if (!dev_counter) return PAM_E_ARG;
     hipLaunchKernelGGL(k_flag_signal, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counter);
+    return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
+}
+extern "C" int pam_flag_signal_mask(void* stream, int32_t* dev_counters, uint32_t mask) {
+    if (!dev_counters || !mask) return PAM_E_ARG;
+    hipLaunchKernelGGL(k_flag_signal_mask, dim3(1), dim3(64), 0, (hipStream_t)stream, dev_counters, mask);
     return hipGetLastError() == hipSuccess ? PAM_OK : PAM_E_HIP;
 }
 extern "C" int pam_flag_gate(void* stream, int32_t* dev_counter, int target, int32_t* dev_err, const uint32_t* dev_max_us, int arrive, int32_t* host_err,

@@ -896,7 +896,7 @@ class HipHRNet(ConvEngine):
     def _flag_begin(self):
         """counters + error word of ONE forward (word 0 = error); zeroed on the caller's stream in front of the fork -- inside a capture the
         fill is a node of the graph, i.e. it runs at every replay"""
-        self._flags = torch.zeros(64, dtype=torch.int32, device=self.device)
+        self._flags = torch.zeros(128, dtype=torch.int32, device=self.device)
         self._flag_next = 1
         if self._keep is not None:
             self._keep.append(self._flags)
@@ -904,13 +904,24 @@ class HipHRNet(ConvEngine):
     def _flag_new(self):
         i = self._flag_next
         self._flag_next += 1
-        assert i < 64
+        assert i < 128
         return i
 
     def _sig(self, i):
         rc = self.lib.pam_flag_signal(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.c_void_p(self._flags.data_ptr() + 4 * i))
         if rc != 0:
             raise _lib.PamError('pam_flag_signal failed (%d)' % rc)
+
+    flag_per_output = False     # round 6 experiment: one counter per OUTPUT of a module (a sum waits for the blocks and chains it reads)
+                                # instead of one per module (every sum waits for every branch's whole tail)
+
+    def _sig_mask(self, base, mask):
+        if not mask:
+            return
+        rc = self.lib.pam_flag_signal_mask(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.c_void_p(self._flags.data_ptr() + 4 * base),
+                                           C.c_uint32(int(mask)))
+        if rc != 0:
+            raise _lib.PamError('pam_flag_signal_mask failed (%d)' % rc)
 
     def _gate(self, i, target, arrive=False):
         rc = self.lib.pam_flag_gate(C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.c_void_p(self._flags.data_ptr() + 4 * i),
@@ -945,7 +956,15 @@ class HipHRNet(ConvEngine):
         fuse = mod['fuse']
         terms = [dict() for _ in fuse]
         flags = self.flags_on and self.multi_stream
-        ctail = self._flag_new() if flags else None
+        per_out = bool(flags and self.flag_per_output)
+        ctail = self._flag_new() if (flags and not per_out) else None
+        cbase, contrib = None, None
+        if per_out:
+            cbase = self._flag_next
+            for _ in fuse:
+                self._flag_new()
+            nb = len(mod['branches'])
+            contrib = [[b for b in range(nb) if b != i and b < len(row) and row[b] is not None] for i, row in enumerate(fuse)]
         for b in [q for q in self.order if q < len(mod['branches'])]:
             with torch.cuda.stream(self._stream(b)):
                 x = xs[b]
@@ -963,6 +982,9 @@ class HipHRNet(ConvEngine):
                     y = self.conv(mg['op'], x, relu=True, relu_from=mg['relu_from'])
                     heads = {i: y[:, off:off + c] for i, off, c, _ in mg['parts']}
                 fmask = 15 if self.fused_sums is True else int(self.fused_sums)   # bit i: output i's sum carries its 1x1 products (k_fuse_sum)
+                if per_out:                                           # the fused sums of finer outputs read this branch's blocks' output itself
+                    self._sig_mask(cbase, sum(1 << i for i, row in enumerate(fuse) if i < b and b < len(row) and row[b] is not None
+                                              and row[b][0] == 'up' and (fmask >> i) & 1 and mod['fsum'][i] is not None))
                 mu = mod['merged_up'].get(b) if (self.merge_fuse and self.merge_up and not fmask) else None
                 if mu is not None:                                    # all 1x1 up-convolutions from this branch in one launch
                     if self.knock_up and b == len(mod['branches']) - 1:   # diagnostics: what the last finisher's tail is worth
@@ -971,6 +993,8 @@ class HipHRNet(ConvEngine):
                         y = self.conv(mu['op'], x)
                     for i, off, c, sh in mu['parts']:
                         terms[i][b] = (y[:, off:off + c], sh)
+                    if per_out:
+                        self._sig_mask(cbase, sum(1 << i for i, _, _, _ in mu['parts']))
                 for i, row in enumerate(fuse):
                     f = row[b] if b < len(row) else None
                     if f is None or (f[0] == 'up' and (mu is not None or (fmask >> i) & 1)):
@@ -983,8 +1007,10 @@ class HipHRNet(ConvEngine):
                         for k, op in enumerate(ops):
                             t = self.conv(op, t, relu=(k0 + k < len(f[1]) - 1))
                         terms[i][b] = (t, 0)
+                    if per_out:
+                        self._sig_mask(cbase, 1 << i)
                 self._st('b%d tail' % b)
-                if flags and b >= len(fuse):
+                if flags and not per_out and b >= len(fuse):
                     self._sig(ctail)                                  # a branch without an output of its own only arrives (the last module of stage 4)
         if not flags:
             self._barrier()
@@ -993,7 +1019,9 @@ class HipHRNet(ConvEngine):
         out = [None] * len(fuse)
         for i in [q for q in self.order if q < len(fuse)]:
             with torch.cuda.stream(self._stream(i)):
-                if flags:
+                if per_out:
+                    self._gate(cbase + i, 1 + len(contrib[i]), arrive=True)   # this output's own producers only
+                elif flags:
                     self._gate(ctail, len(mod['branches']), arrive=True)   # this stream's chain is done; wait for every other branch's
                 tl = [terms[i][j] for j in sorted(terms[i])]
                 fs = mod['fsum'][i] if ((15 if self.fused_sums is True else int(self.fused_sums)) >> i) & 1 else None

@@ -67,6 +67,15 @@ def section_flags(x, ref):
                 torch.cuda.synchronize()
                 assert torch.equal(yf, ye), (name, n)
         assert int(e._flag_host_np[0]) == 0 and int(e.void_word.item()) == 0
+    # the experiment of round 6 (off: +0.2 ... +0.7 % per forward): one counter per OUTPUT of a module, several signalled per launch
+    # (pam_flag_signal_mask) -- a sum then waits only for the blocks and chains it reads; same launches, same bits
+    po = hrnet.HRNetPose(48, 17, None, use_graph=True)
+    po.hip.flag_per_output = True
+    po.flag_race = None
+    for _ in range(3):
+        yp = po.features(x).clone(); torch.cuda.synchronize()
+        assert torch.equal(ref, yp)
+    assert po.flag_synced[(5, 'features', 0)] is True and int(po._flag_host_np[0]) == 0
     print('FLAGS-OK', flush=True)
     return b
 
