@@ -52,6 +52,46 @@ __device__ inline double track_det_affinity(const float* __restrict__ P, const d
     return aff;
 }
 
+// The same value for the MP detection slots of ONE (view, track) pair held by MP neighbouring lanes (MP = 8, 16 or 32; round 6): the
+// track's 17 re-projections -- each with its fp64 division -- are computed ONCE per group, joint j by the group's lane j % MP, and handed
+// round through the wave; every lane then runs track_det_affinity's own loop (same expressions, same joint order) on the received
+// (u, v).  All lanes of the wave must call it; `live` = this lane has a detection to score.
+template <int MP>
+__device__ inline double track_det_affinity_group(const float* __restrict__ P, const double* __restrict__ pose3d,
+                                                  const double* __restrict__ det, double alpha_dt, double exp_ldt, int gate, bool live) {
+    constexpr int Q = (J + MP - 1) / MP;
+    const int lane = threadIdx.x & 63, k = lane & (MP - 1), base = lane - k;
+    double pu[Q], pv[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int j = k + q * MP;
+        pu[q] = pv[q] = 0.0;
+        if (j < J) project_point(P, pose3d[j * 3 + 0], pose3d[j * 3 + 1], pose3d[j * 3 + 2], pu[q], pv[q]);
+    }
+    double sum = 0.0;
+    int cnt = 0;
+    const double inv_alpha_dt = 1.0 / alpha_dt;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {                        // (static register index per q; the walk over a row's lanes stays a loop)
+#pragma unroll 1
+        for (int m = 0; m < MP && q * MP + m < J; ++m) {
+            const int j = q * MP + m;
+            const double u = __shfl(pu[q], base + m);
+            const double v = __shfl(pv[q], base + m);
+            if (live) {
+                double dy = v - det[j * 3 + 0];
+                double dx = u - det[j * 3 + 1];
+                double c = 1.0 - sqrt(dy * dy + dx * dx) * inv_alpha_dt;
+                if (c > 0.0) { sum += c; ++cnt; }
+            }
+        }
+    }
+    double aff = (cnt > gate) ? sum / (double)cnt : 0.0;
+    aff = aff / exp_ldt;
+    if (aff != aff) aff = 0.0;
+    return aff;
+}
+
 // ---- a5: rectangular LSAP (SciPy linear_sum_assignment restated), call sites IterativeTracker.py:79,150 ---------
 struct LsapScratch {         // N = max(nr, nc) entries each
     double* u; double* v; double* spc;

@@ -168,7 +168,7 @@ __device__ __forceinline__ double now_s() { return (double)__builtin_amdgcn_s_me
 // workgroup walked in 54 passes of dependent L2 loads, 136 of its 297 us) spread over MANY workgroups, 3 = P4c-P7.  The split forms keep
 // all scratch and the integer state in global memory (hot_in_lds = 0); one scene per handle.
 template <int NTHREADS, int PART = 0>
-__global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
+__global__ __launch_bounds__(NTHREADS, 4) void k_frame(FrameArgs A) {      // 4 waves per SIMD: four 256-thread scenes per CU (<= 128 VGPRs)
     const Dims d = A.d;
     const int C = d.C, MAXP = d.MAXP, MAXT = d.MAXT, HCAP = d.HCAP, MAXH = d.MAXH;
     const int sidx = PART == 2 ? 0 : blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
@@ -264,6 +264,28 @@ __global__ __launch_bounds__(NTHREADS) void k_frame(FrameArgs A) {
     __syncthreads();
 
     // ---- P1: re-projection affinity for every (view, track, detection) (:137-149) ----------------------------------
+    if (MAXP == 8 || MAXP == 16 || MAXP == 32) {
+        // the MAXP slots of a (view, track) pair sit in MAXP neighbouring lanes: the track's 17 re-projections are computed once per
+        // group and shared through the wave (track_det_affinity_group) instead of once per detection; whole waves iterate together
+        const int total = C * nT * MAXP;
+        for (int it = tid; it - (tid & 63) < total; it += NT) {
+            const bool in = it < total;
+            const int ic = in ? it : 0;
+            const int v = ic / (nT * MAXP), r = ic % (nT * MAXP), i = r / MAXP, k = r % MAXP;
+            const bool live = in && k < NDET(v);
+            const int s = st.order[i];
+            const int newest = (st.h_head[s] + st.h_len[s] - 1) % HCAP;
+            const int dt = ws.dt[i];
+            const double e = (dt >= 0 && dt < PAM_EXP_TABLE) ? prm.exp_lambda_a[dt] : exp(prm.lambda_a * (double)dt);
+            const float* Pv = cs.P + v * 12;
+            const double* X3 = st.hist + ((size_t)s * HCAP + newest) * J3;
+            const double* dk = DET(v, live ? k : 0);
+            const double a = MAXP == 8 ? track_det_affinity_group<8>(Pv, X3, dk, prm.alpha2d * (double)dt, e, prm.count_gate, live)
+                           : MAXP == 16 ? track_det_affinity_group<16>(Pv, X3, dk, prm.alpha2d * (double)dt, e, prm.count_gate, live)
+                                        : track_det_affinity_group<32>(Pv, X3, dk, prm.alpha2d * (double)dt, e, prm.count_gate, live);
+            if (live) ws.aff[((size_t)v * MAXT + i) * MAXP + k] = a;
+        }
+    } else
     for (int it = tid; it < C * nT * MAXP; it += NT) {
         const int v = it / (nT * MAXP), r = it % (nT * MAXP), i = r / MAXP, k = r % MAXP;
         if (k >= NDET(v)) continue;
