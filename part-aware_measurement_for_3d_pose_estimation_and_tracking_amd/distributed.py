@@ -19,9 +19,12 @@ def device_identity(device):
     UUID where PyTorch reports one, else its PCI location."""
     import socket
     p = torch.cuda.get_device_properties(device)
-    ident = getattr(p, 'uuid', None)
-    if ident is None or str(ident) in ('', 'None'):
-        ident = (getattr(p, 'pci_domain_id', None), getattr(p, 'pci_bus_id', None), getattr(p, 'pci_device_id', None), p.name)
+    # everything that can tell two devices apart, together: a UUID that a runtime reports as zeros for every device, or PCI fields a
+    # build does not expose, must not merge two GPUs into one (that would only switch the flags off -- safe, but silent); with none of
+    # them available the visible index decides, which calls per-rank HIP_VISIBLE_DEVICES "shared": the safe side
+    ident = (str(getattr(p, 'uuid', None)), getattr(p, 'pci_domain_id', None), getattr(p, 'pci_bus_id', None), getattr(p, 'pci_device_id', None))
+    if all(x in (None, 'None', '') for x in ident) or (ident[1] is None and set(ident[0]) <= set('0-')):
+        ident = ident + (p.name, torch.device(device).index)
     return socket.gethostname(), str(ident)
 
 

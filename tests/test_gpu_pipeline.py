@@ -288,3 +288,10 @@ def test_input_guard_skips_frames_leaves_the_state_untouched_and_names_the_first
     new.gather.send[1, md, 0, 1] = 0.0
     for t in range(20, F):
         same(step(t), want[t])
+
+
+def test_device_identity_is_stable_and_specific():
+    """distributed.device_identity: what ranks_share_a_device compares -- host name + every device-distinguishing field PyTorch reports."""
+    from pam.distributed import device_identity
+    a, b = device_identity(torch.device('cuda:0')), device_identity(torch.device('cuda:0'))
+    assert a == b and len(a) == 2 and isinstance(a[1], str) and len(a[1]) > 8
