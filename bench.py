@@ -851,6 +851,7 @@ def surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, K
         model = ivclabpose({'NAME': ''}, None, dict(mcfg, NAME='Iterative'), conf, max_dets=max_dets, max_tracks=16, device=pipe.device.index)
     model.pose_model = pipe.net                       # same network object (weights, packed images, graphs)
     model.pose_model.max_dets = max_dets
+    model.tracker.set_input_guard(pipe.net)           # (what ivclabpose's constructor does when it builds the pose network itself)
     model.cameras = cams
     model.tracker.set_cameras(cams)
     C = len(cams)

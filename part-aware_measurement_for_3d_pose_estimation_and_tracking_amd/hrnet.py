@@ -469,8 +469,10 @@ class HRNetPose(object):
             self._graphs[(n, kind, slot)] = g
             self._alt[(n, kind, slot)] = alt
             self.flag_synced[(n, kind, slot)] = flags is not None if alt is None else bool(raced['kept'][self.flag_race])
-        if self.check_void() and (n, kind, slot) not in self._graphs:     # (the race's replays gave up: this forward again, with stream events)
-            return self._run(x, kind, slot)
+        if self.check_void():                              # (a replay of the capture-time race gave up: the switch to stream events has
+            g = self._graphs.get((n, kind, slot))          #  replaced or dropped this forward's flagged capture)
+            if g is None:
+                return self._run(x, kind, slot)
         alt = self._alt.get((n, kind, slot))
         if alt is not None:                                # two forms of this forward: the one that is faster the way this object is used now
             g = alt['flags' if self.flag_timing[n]['kept'][self.flag_race or 'throughput'] else 'events']
