@@ -181,6 +181,36 @@ __device__ inline int lsap_solve(int nr0, int nc0, const double* cost, int ld, d
 // replaces the running minimum when strictly lower, or equal AND unassigned -- means: the LAST unassigned minimal column in list order
 // if there is one, else the FIRST minimal column; list order is kept per lane (`pos`; removal moves the last entry into the hole).
 // All 64 lanes must call it (max(nr0, nc0) <= 64); lane L < returned n holds pair (row, col) L of the row-sorted result.
+// cross-lane helpers of the wave solver: a value of a wave-UNIFORM lane is a v_readlane (no LDS-pipe round trip like ds_bpermute), and a
+// reduction over the 16 lanes of a DPP row is four row rotations
+__device__ __forceinline__ int lane_bcast_i(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
+__device__ __forceinline__ double lane_bcast_d(double x, int src) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+#define PAM_DPP_ROR(x, n) __builtin_amdgcn_update_dpp(0, (x), 0x120 + (n), 0xF, 0xF, false)
+__device__ __forceinline__ double row16_min_d(double v) {
+#define PAM_STEP(n) { const unsigned long long b = __builtin_bit_cast(unsigned long long, v); \
+        const unsigned lo = (unsigned)PAM_DPP_ROR((int)(unsigned)b, n), hi = (unsigned)PAM_DPP_ROR((int)(unsigned)(b >> 32), n); \
+        const double o = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); v = o < v ? o : v; }
+    PAM_STEP(8) PAM_STEP(4) PAM_STEP(2) PAM_STEP(1)
+#undef PAM_STEP
+    return v;
+}
+__device__ __forceinline__ int row16_max_i(int v) {
+    int o;
+    o = PAM_DPP_ROR(v, 8); v = o > v ? o : v; o = PAM_DPP_ROR(v, 4); v = o > v ? o : v;
+    o = PAM_DPP_ROR(v, 2); v = o > v ? o : v; o = PAM_DPP_ROR(v, 1); v = o > v ? o : v;
+    return v;
+}
+__device__ __forceinline__ int row16_min_i(int v) {
+    int o;
+    o = PAM_DPP_ROR(v, 8); v = o < v ? o : v; o = PAM_DPP_ROR(v, 4); v = o < v ? o : v;
+    o = PAM_DPP_ROR(v, 2); v = o < v ? o : v; o = PAM_DPP_ROR(v, 1); v = o < v ? o : v;
+    return v;
+}
+
 __device__ inline int lsap_solve_wave(int nr0, int nc0, const double* cost, int ld, double sign, int* rows_out, int* cols_out,
                                       int& my_row, int& my_col) {
     const int lane = threadIdx.x & 63;
@@ -190,6 +220,7 @@ __device__ inline int lsap_solve_wave(int nr0, int nc0, const double* cost, int 
     const int nr = tr ? nc0 : nr0, nc = tr ? nr0 : nc0;
     int width = 1;
     while (width < nc) width <<= 1;                      // the reductions run over the lanes that can hold a column
+    const bool row16 = width <= 16;                      // ... one DPP row: rotations instead of ds_bpermute exchanges
     const double INF = __builtin_huge_val();
     double u = 0.0, v = 0.0, spc = INF;
     int col4row = -1, row4col = -1, path = -1, pos = -1;
@@ -201,7 +232,7 @@ __device__ inline int lsap_solve_wave(int nr0, int nc0, const double* cost, int 
         double min_val = 0.0;
         while (sink == -1) {
             if (lane == i) SR = true;
-            const double ui = __shfl(u, i);
+            const double ui = lane_bcast_d(u, i);
             const bool active = pos >= 0;
             double sp = spc;
             if (active) {
@@ -210,17 +241,21 @@ __device__ inline int lsap_solve_wave(int nr0, int nc0, const double* cost, int 
                 if (r < sp) { path = i; spc = r; sp = r; }
             }
             double lowest = active ? sp : INF;
-            for (int m = 1; m < width; m <<= 1) { const double o = __shfl_xor(lowest, m); lowest = o < lowest ? o : lowest; }
+            if (row16) lowest = row16_min_d(lowest);
+            else for (int m = 1; m < width; m <<= 1) { const double o = __shfl_xor(lowest, m); lowest = o < lowest ? o : lowest; }
+            lowest = lane_bcast_d(lowest, 0);
             if (lowest == INF) return -1;
             const bool ismin = active && sp == lowest;
             const bool unas = ismin && row4col == -1;
             const bool anyun = __ballot(unas) != 0ull;
             // the chosen list position: max over the unassigned minima, else min over the minima
             int key = anyun ? (unas ? pos : -1) : (ismin ? pos : 0x7fffffff);
-            for (int m = 1; m < width; m <<= 1) { const int o = __shfl_xor(key, m); key = anyun ? (o > key ? o : key) : (o < key ? o : key); }
+            if (row16) key = anyun ? row16_max_i(key) : row16_min_i(key);
+            else for (int m = 1; m < width; m <<= 1) { const int o = __shfl_xor(key, m); key = anyun ? (o > key ? o : key) : (o < key ? o : key); }
+            key = lane_bcast_i(key, 0);
             const int jsel = __ffsll((long long)__ballot(active && pos == key)) - 1;
             min_val = lowest;
-            const int r4c = __shfl(row4col, jsel);
+            const int r4c = lane_bcast_i(row4col, jsel);
             if (r4c == -1) sink = jsel; else i = r4c;
             --num_rem;                                   // remaining[index] = remaining[--num_rem]
             if (lane == jsel) { SC = true; pos = -1; }
@@ -234,9 +269,9 @@ __device__ inline int lsap_solve_wave(int nr0, int nc0, const double* cost, int 
         // augment along the predecessor chain
         int j = sink;
         for (;;) {
-            const int ii = __shfl(path, j);
+            const int ii = lane_bcast_i(path, j);
             if (lane == j) row4col = ii;
-            const int t = __shfl(col4row, ii);
+            const int t = lane_bcast_i(col4row, ii);
             if (lane == ii) col4row = j;
             j = t;
             if (ii == cur) break;
