@@ -479,6 +479,38 @@ __device__ inline void min_right_singular_vector(double W[4][4], double out[4]) 
     for (int r = 0; r < 4; ++r) out[r] = (k == 0) ? E[r][0] : (k == 1) ? E[r][1] : (k == 2) ? E[r][2] : E[r][3];
 }
 
+// The same vector for an UPPER-TRIANGULAR W (what the Givens folds leave) by inverse iteration on W^T W with two triangular solves per
+// step -- never forming the product: x <- W^-1 (W^-T x).  A triangulation's system has ONE small singular value (the noise) below three
+// large ones, so each step shrinks the error by (s4 / s3)^2: two or three steps against the 5-7 sweeps x 6 rotations (each with a sqrt,
+// a division and an rsqrt in fp64) of the Jacobi above, which stays as the fall-back for a zero pivot or a slow case (nearly parallel
+// rays: s3 ~ s4).  -> true when it converged.
+__device__ inline bool min_right_singular_vector_tri(const double W[4][4], double out[4]) {
+    const double d0 = W[0][0], d1 = W[1][1], d2 = W[2][2], d3 = W[3][3];
+    if (d0 == 0.0 || d1 == 0.0 || d2 == 0.0 || d3 == 0.0) return false;
+    const double i0 = 1.0 / d0, i1 = 1.0 / d1, i2 = 1.0 / d2, i3 = 1.0 / d3;
+    double x0 = 0.5, x1 = 0.5, x2 = 0.5, x3 = 0.5;
+    for (int it = 0; it < 8; ++it) {
+        // W^T y = x (forward), then W z = y (backward)
+        const double y0 = x0 * i0;
+        const double y1 = (x1 - W[0][1] * y0) * i1;
+        const double y2 = (x2 - W[0][2] * y0 - W[1][2] * y1) * i2;
+        const double y3 = (x3 - W[0][3] * y0 - W[1][3] * y1 - W[2][3] * y2) * i3;
+        const double z3 = y3 * i3;
+        const double z2 = (y2 - W[2][3] * z3) * i2;
+        const double z1 = (y1 - W[1][2] * z2 - W[1][3] * z3) * i1;
+        const double z0 = (y0 - W[0][1] * z1 - W[0][2] * z2 - W[0][3] * z3) * i0;
+        const double nn = z0 * z0 + z1 * z1 + z2 * z2 + z3 * z3;
+        if (!(nn > 0.0) || nn == __builtin_huge_val()) return false;
+        const double in_ = rsqrt(nn);
+        double n0 = z0 * in_, n1 = z1 * in_, n2 = z2 * in_, n3 = z3 * in_;
+        // (z = (W^T W)^-1 x keeps x's orientation: <z, x> > 0, so successive iterates are compared as they are)
+        const double e = fmax(fmax(fabs(n0 - x0), fabs(n1 - x1)), fmax(fabs(n2 - x2), fabs(n3 - x3)));
+        x0 = n0; x1 = n1; x2 = n2; x3 = n3;
+        if (it > 0 && e <= 1e-15) { out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3; return true; }
+    }
+    return false;
+}
+
 // one joint: views listed in sel_cid[0..V) with ages T -> weight w_t[T]; keep = bitmask over the V list positions;
 // pose(v) returns the (y,x,score) row of list position v for this joint.  dlt_fold folds the kept views v = v0, v0+vstep, ...
 // into the triangular factor R (so several lanes can share one joint); dlt_merge folds another partial factor in.
@@ -523,7 +555,7 @@ __device__ inline void dlt_merge(double R[4][4], const double* o) {
 }
 __device__ inline void dlt_solve(double R[4][4], double out[3]) {
     double X[4];
-    min_right_singular_vector(R, X);
+    if (!min_right_singular_vector_tri(R, X)) min_right_singular_vector(R, X);
     out[0] = X[0] / X[3]; out[1] = X[1] / X[3]; out[2] = X[2] / X[3];
 }
 template <typename PoseFn>
