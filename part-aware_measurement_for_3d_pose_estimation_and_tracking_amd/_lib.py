@@ -295,6 +295,18 @@ class Handle(object):
         untouched): the word is raised by the producer of the keypoints (HRNetPose.void_word).  None / 0 removes the guard."""
         self._chk(self.lib.pam_set_input_guard(self._h, C.c_void_p(dev_word_ptr or None)))
 
+    def pinned_record(self):
+        """(keep, out_i, out_d): ONE pinned host buffer laid out like the device record (int32 section padded to 8 bytes, float64 section
+        behind it) and NumPy views of its two sections -- ``fetch`` into them is a single device -> host copy."""
+        import torch
+        L = self.layout
+        ib = (4 * self.n_scenes * L.int_words + 7) & ~7
+        buf = torch.zeros(ib + 8 * self.n_scenes * L.dbl_words, dtype=torch.uint8).pin_memory()
+        a = buf.numpy()
+        oi = a[:4 * self.n_scenes * L.int_words].view(np.int32).reshape(self.n_scenes, L.int_words)
+        od = a[ib:].view(np.float64).reshape(self.n_scenes, L.dbl_words)
+        return buf, oi, od
+
     def fetch(self, stream, out_i=None, out_d=None):
         out_i = self.out_i if out_i is None else out_i
         out_d = self.out_d if out_d is None else out_d

@@ -932,10 +932,14 @@ extern "C" int pam_create(PamHandle** out, int device, int n_views, int max_dets
     CR(hipMemset(h->d_ws, 0, h->ws_stride * d.S));
     CR(hipMalloc(&h->d_ndet, sizeof(int) * d.S * d.C));
     CR(hipMalloc(&h->d_det, sizeof(double) * (size_t)d.S * d.C * d.MAXP * J3));
-    CR(hipMalloc(&h->d_out_i, sizeof(int) * (size_t)d.S * ol.int_words));
-    CR(hipMalloc(&h->d_out_d, sizeof(double) * (size_t)d.S * ol.dbl_words));
-    CR(hipMemset(h->d_out_i, 0, sizeof(int) * (size_t)d.S * ol.int_words));
-    CR(hipMemset(h->d_out_d, 0, sizeof(double) * (size_t)d.S * ol.dbl_words));
+    {   // the record's two sections in ONE allocation, the float64 section behind the int32 one (padded to 8 bytes): a host that lays its
+        // pinned landing buffer out the same way gets the record in ONE copy (pam_fetch; Handle.pinned_record)
+        const size_t ib = (sizeof(int) * (size_t)d.S * ol.int_words + 7) & ~(size_t)7, db = sizeof(double) * (size_t)d.S * ol.dbl_words;
+        char* rec = nullptr;
+        CR(hipMalloc(&rec, ib + db));
+        CR(hipMemset(rec, 0, ib + db));
+        h->d_out_i = (int*)rec; h->d_out_d = (double*)(rec + ib);
+    }
     CR(hipMalloc(&h->d_op, h->op_bytes));
 #undef CR
     *out = h;
@@ -947,7 +951,7 @@ extern "C" int pam_destroy(PamHandle* h) {
     hipSetDevice(h->device);
     hipFree(h->d_prm); hipFree(h->d_P); hipFree(h->d_F); hipFree(h->d_RK); hipFree(h->d_pos);
     hipFree(h->d_state); hipFree(h->d_ws); hipFree(h->d_ndet); hipFree(h->d_det);
-    hipFree(h->d_out_i); hipFree(h->d_out_d); hipFree(h->d_op);
+    hipFree(h->d_out_i); hipFree(h->d_op);                  // (d_out_d lives in d_out_i's allocation)
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
     return PAM_OK;
@@ -1046,8 +1050,13 @@ extern "C" int pam_frame_dev_views(PamHandle* h, void* stream, int frame_id, con
 extern "C" int pam_fetch(PamHandle* h, void* stream, int32_t* host_out_i, double* host_out_d) {
     if (!h) return PAM_E_ARG;
     hipStream_t s = (hipStream_t)stream;
+    const size_t ib = (size_t)((char*)h->d_out_d - (char*)h->d_out_i), db = sizeof(double) * (size_t)h->d.S * h->ol.dbl_words;
+    if (host_out_i && host_out_d && (char*)host_out_d == (char*)host_out_i + ib) {                 // one landing buffer in the device layout: one copy
+        HIPCHK(h, hipMemcpyAsync(host_out_i, h->d_out_i, ib + db, hipMemcpyDeviceToHost, s));
+        return PAM_OK;
+    }
     if (host_out_i) HIPCHK(h, hipMemcpyAsync(host_out_i, h->d_out_i, sizeof(int) * (size_t)h->d.S * h->ol.int_words, hipMemcpyDeviceToHost, s));
-    if (host_out_d) HIPCHK(h, hipMemcpyAsync(host_out_d, h->d_out_d, sizeof(double) * (size_t)h->d.S * h->ol.dbl_words, hipMemcpyDeviceToHost, s));
+    if (host_out_d) HIPCHK(h, hipMemcpyAsync(host_out_d, h->d_out_d, db, hipMemcpyDeviceToHost, s));
     return PAM_OK;
 }
 

@@ -60,9 +60,8 @@ class FramePipeline(object):
         # decode target: this rank's views only -- the leading records of the exchange's send buffer, (len(mine), max_dets + 1, 17, 3):
         # slot stride max_dets + 1, the extra row carries the view's detection count (ViewGather)
         self.det_local = self.gather.det_local
-        L = self.handle.layout
-        self.out_i = torch.zeros((1, L.int_words), dtype=torch.int32).pin_memory()
-        self.out_d = torch.zeros((1, L.dbl_words), dtype=torch.float64).pin_memory()
+        self._rec_keep, oi, od = self.handle.pinned_record()           # one pinned buffer in the device record's layout: one copy per fetch
+        self.out_i, self.out_d = torch.from_numpy(oi), torch.from_numpy(od)
         self.ev = None
         self.track_stream, self.track_overlaps = self._pick_track_stream() if overlap_tracker else (None, False)
         self.ev_pose, self.ev_track, self._track_pending = torch.cuda.Event(), torch.cuda.Event(), False

@@ -79,10 +79,8 @@ class IterativeTracker(object):
         self._ndet = np.zeros((1, n_views), dtype=np.int32)
         self._det = np.zeros((1, n_views, self.max_dets, NUM_JOINTS, 3), dtype=np.float64)
         # the record of the device-side step lands in PINNED host memory: a pageable destination makes the copy a staged, blocking one
-        import torch
-        L = self.handle.layout
-        self._rec_i = torch.zeros((1, L.int_words), dtype=torch.int32).pin_memory()
-        self._rec_d = torch.zeros((1, L.dbl_words), dtype=torch.float64).pin_memory()
+        # (one buffer in the device record's layout: one copy per frame instead of two)
+        self._rec_keep, self._rec_i, self._rec_d = self.handle.pinned_record()
         if self._guard is not None:
             self.handle.set_input_guard(self._guard.void_word.data_ptr())
 
@@ -143,7 +141,7 @@ class IterativeTracker(object):
         if tuple(dev_det.shape) != (self.cam_num, self.max_dets, NUM_JOINTS, 3) or dev_det.dtype != torch.float64 or \
                 dev_n_det.dtype != torch.int32 or not dev_det.is_contiguous():
             raise _lib.PamError('device detections %s do not match the tracker (%d views, max_dets=%d)' % (tuple(dev_det.shape), self.cam_num, self.max_dets))
-        oi, od = self._rec_i.numpy(), self._rec_d.numpy()
+        oi, od = self._rec_i, self._rec_d
         for attempt in (0, 1):
             st = torch.cuda.current_stream(dev_det.device).cuda_stream
             self.handle.frame_dev(st, frame_id, dev_n_det.data_ptr(), dev_det.data_ptr())
