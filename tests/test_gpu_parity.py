@@ -98,6 +98,13 @@ def test_lsap_fuzz_vs_oracle(lib):
         r0, c0 = O.lsap(cost)
         r1, c1 = h.op_lsap(cost)
         assert np.array_equal(r0, r1) and np.array_equal(c0, c1), cost
+    # the frame kernel's solver is a WAVE per problem (round 6): up to 16 columns its reductions are DPP row rotations, up to 64
+    # cross-lane shuffles; beyond 64 the single-lane walk (the hypothesis step's form) -- every path against SciPy's order, ties included
+    for it, (n, m) in enumerate([(17, 17), (20, 31), (31, 20), (33, 64), (64, 40), (64, 64), (5, 40), (40, 5), (70, 66), (66, 70), (3, 65)]):
+        cost = rng.normal(size=(n, m)) if it % 2 == 0 else rng.integers(0, 4, size=(n, m)).astype(float)
+        r0, c0 = O.lsap(cost)
+        r1, c1 = h.op_lsap(cost)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (n, m)
     r, c = h.op_lsap(np.zeros((0, 3)))
     assert len(r) == 0
     h.close()
