@@ -555,7 +555,11 @@ __device__ inline void dlt_merge(double R[4][4], const double* o) {
 }
 __device__ inline void dlt_solve(double R[4][4], double out[3]) {
     double X[4];
+#ifdef PAM_DLT_JACOBI_ONLY                               // check build: the fall-back alone (tools/ab_build.sh PAM_DLT_JACOBI_ONLY '<parity tests>')
+    min_right_singular_vector(R, X);
+#else
     if (!min_right_singular_vector_tri(R, X)) min_right_singular_vector(R, X);
+#endif
     out[0] = X[0] / X[3]; out[1] = X[1] / X[3]; out[2] = X[2] / X[3];
 }
 template <typename PoseFn>
