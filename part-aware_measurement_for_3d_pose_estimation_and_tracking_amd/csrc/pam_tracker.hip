@@ -548,7 +548,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_frame(FrameArgs A) {      // 4 
     // ---- P5: init_target_GD (:52-113): greedy cross-view hypotheses from the unmatched detections ------------
     if (tid == 0) ws.misc[0] = 0;
     __syncthreads();
-    if (C >= 2) {
+    // (steady state: every detection was matched -- no hypothesis can form, and the block below is 2 C + 5 workgroup barriers: 62 on the
+    //  31-camera rig, 9 of its 143 us)
+    int um_total = 0;
+    for (int v = 0; v < C; ++v) um_total += ws.um_n[v];
+    if (C >= 2 && um_total > 0) {
         if (tid == 0) {
             int nh = 0;
             for (int k = 0; k < ws.um_n[0]; ++k) {
@@ -718,12 +722,17 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_frame(FrameArgs A) {      // 4 
         o[0] = st.track_id[s]; o[1] = st.state[s]; o[2] = st.hits[s]; o[3] = st.age[s]; o[4] = st.tsu[s];
         o[5] = (st.tsu[s] == 0 && st.state[s] == CONFIRMED) ? 1 : 0;
         o[6] = st.p2d_n[s]; o[7] = st.jv_V[s]; o[8] = st.h_len[s]; o[9] = st.hist_time[s * HCAP + newest];
-        for (int c = 0; c < C; ++c) {
+    }
+    for (int it = tid; it < nOut * (C + J); it += NT) {    // the per-view and per-joint fields: a lane per (track, field), not a lane per track
+        const int i = it / (C + J), c = it % (C + J), s = st.order[i];
+        int* o = out_i + ol.hdr_words + i * ol.trk_words;
+        if (c < C) {
             o[ol.off_order + c] = (c < st.p2d_n[s]) ? st.p2d_order[s * C + c] : -1;
             o[ol.off_matched + c] = st.cur_det[s * C + c];
             o[ol.off_time2d + c] = st.p2d_time[s * C + c];
+        } else {
+            o[ol.off_nviews + (c - C)] = st.jv_count[s * J + (c - C)];
         }
-        for (int j = 0; j < J; ++j) o[ol.off_nviews + j] = st.jv_count[s * J + j];
     }
     for (int it = tid; it < nOut * J3; it += NT) {
         const int i = it / J3, e = it % J3, s = st.order[i];
