@@ -884,11 +884,15 @@ def surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, K
             one(t)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        t_half = None
         for t in range(W, W + K):
+            if t == W + K // 2:
+                t_half = time.perf_counter()             # (both halves are reported: a host hiccup of a few ms shows as a gap between them)
             r = one(t)
             emitted += len(r[5])
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        halves = [(K // 2) / (t_half - t0), (K - K // 2) / (t0 + el - t_half)] if t_half is not None else None
     finally:
         pipe.net.flag_race = race_mode
     # where a surface step goes: the forward alone, one replay at a time, in the form this loop used (device time; the crop / head / frame
@@ -902,7 +906,7 @@ def surface_run(torch, synth, pipe, cams, cfg, conf, seq, inp, size, max_dets, K
         form = ('flags' if pipe.net.flag_timing[nb]['kept']['serial'] else 'events') if alt is not None else ('flags' if pipe.net.flag_synced.get(key) else 'events')
         g = alt[form][0] if alt is not None else pipe.net._graphs[key][0]
         fwd_ms = float(np.median([pipe.net._replay_ms(g, 'serial') for _ in range(5)]))
-    return {'value': K / el, 'unit': 'frames/s', 'ms_per_step': el / K * 1e3, 'steps': K, 'emitted_poses': emitted,
+    return {'value': K / el, 'unit': 'frames/s', 'ms_per_step': el / K * 1e3, 'steps': K, 'emitted_poses': emitted, 'halves_fps': halves,
             'forward_form': form, 'forward_ms_one_at_a_time': fwd_ms, 'host_and_rest_ms': (el / K * 1e3 - fwd_ms) if fwd_ms else None,
             'what': 'ivclabpose.PersonPoseDetect + PersonTrack_Project3DPose per frame (host lists out of predict, 9-tuple out of the tracker; '
                     'keypoints handed over on the device)'}
