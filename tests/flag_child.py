@@ -202,7 +202,7 @@ def _rig(size):
     return seq, cams, cfg, conf, meta
 
 
-def section_pipeline(kill=19):
+def section_pipeline(kill=19, exchange='torch', records_only=False):
     """FramePipeline with the tracker of frame t under frame t + 1's conv stack and the host three frames ahead: the forward of frame
     `kill` loses its gates.  The frame kernel must skip that frame AND the ones issued behind it, results() must raise FrameVoid(first =
     kill), and the run re-submitted from there must produce, frame by frame, the records of a pipeline that never saw a time-out."""
@@ -217,8 +217,14 @@ def section_pipeline(kill=19):
         ref.track_step(t, torch.tensor(n_det_all[t], dtype=torch.int32, device=dev), torch.tensor(det_all[t], dtype=torch.float64, device=dev))
         want.append(ref.results())
     net = hrnet.HRNetPose(48, 17, None, use_graph=True, max_dets=md)
-    pipe = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, net=net, overlap_tracker=True)
+    pipe = FramePipeline(cams, cfg, conf, (meta['h'], meta['w']), max_dets=md, net=net, overlap_tracker=True, exchange=exchange)
     net.flag_race = None                                # keep the flagged captures whatever the race says on this box
+    if records_only:
+        # the sharded mechanism alone (row e's default path, flags ON, in one process): the exchange runs through the library's own RCCL
+        # all-gather on a one-rank communicator, the frame kernel reads the gathered records in place, and ONLY the void flag that
+        # travels inside the records protects the tracker (the handle's own guard is taken away)
+        pipe.handle.set_input_guard(None)
+        assert pipe.gather.recv.data_ptr() != pipe.gather.send.data_ptr()
     g = torch.Generator().manual_seed(5)
     frames = torch.randint(0, 256, (C, meta['h'], meta['w'], 3), dtype=torch.uint8, generator=g).to(dev)
     ptrs = torch.tensor([frames[v].data_ptr() for v in range(C)], dtype=torch.int64, device=dev)
@@ -265,7 +271,7 @@ def section_pipeline(kill=19):
     assert voids == [(kill, kill + 2 - (kill % 3))], voids
     assert net.flag_timeouts == 1 and not net.void_pending and int(net.void_word.item()) == 0
     assert checked >= F // 3
-    print('PIPELINE-OK voids=%s' % voids, flush=True)
+    print('PIPELINE-%sOK voids=%s' % ('RECORDS-' if records_only else '', voids), flush=True)
 
 
 def section_memory(size='S2'):
@@ -299,6 +305,7 @@ def main():
         section_surface(True)
     if 'pipeline' in want:
         section_pipeline()
+        section_pipeline(exchange='abi', records_only=True)
     for w in sorted(want):
         if w.startswith('memory'):
             section_memory(w.split(':')[1] if ':' in w else 'S2')

@@ -44,6 +44,13 @@ def test_gate_time_out_inside_the_pipelined_loop_skips_frames_and_names_where_to
     _has(child, 'PIPELINE-OK')
 
 
+def test_the_void_flag_inside_the_exchanged_records_protects_every_replica(child):
+    """Row (e)'s default path in one process -- flags on, view records through the library's RCCL all-gather (one-rank communicator), the
+    frame kernel reading the gathered buffer in place -- with the handle's own guard removed: the flag that travels in the records alone
+    makes the tracker skip the void frames, and the re-submitted run equals a run that never saw a time-out."""
+    _has(child, 'PIPELINE-RECORDS-OK')
+
+
 def test_child_ran_to_its_end(child):
     assert child.returncode == 0 and 'CHILD-DONE' in child.stdout, child.stderr[-3000:]
 
