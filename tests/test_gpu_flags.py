@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 @pytest.fixture(scope='module')
 def child():
-    out = subprocess.run([sys.executable, os.path.join(HERE, 'flag_child.py')], capture_output=True, text=True, timeout=1500)
+    out = subprocess.run([sys.executable, os.path.join(HERE, 'flag_child.py')], capture_output=True, text=True, timeout=400)
     sys.stderr.write(out.stdout[-3000:])
     return out
 
@@ -57,7 +57,7 @@ def test_child_ran_to_its_end(child):
 
 def test_prewarmed_pipeline_memory_is_reported():
     """Replay cache + arena of a prewarmed S2 pipeline with both forms of every flagged bucket alive (a fresh child of its own)."""
-    out = subprocess.run([sys.executable, os.path.join(HERE, 'flag_child.py'), 'memory'], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(HERE, 'flag_child.py'), 'memory'], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'MEMORY-OK' in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
     line = [l for l in out.stdout.splitlines() if l.startswith('MEMORY-OK')][0]
     sys.stderr.write(line + '\n')
